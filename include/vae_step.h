@@ -1,0 +1,126 @@
+/* C ABI of the MI355X-native VanillaVAE training step (libvae_step_gfx950.so).
+ *
+ * The reference has no FFI / plugin interface: its hot path is the
+ * Python call surface models.VanillaVAE.{forward,loss} + train.train_one_epoch,
+ * dispatching to PyTorch ATen.  This library sits BENEATH that surface; each entry
+ * point names the reference lines whose arithmetic it replaces.  Paths are relative
+ * to /root/reference/midi_autoencoder.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  All tensor memory
+ * (parameters, gradients, optimiser state, inputs, outputs) is owned by the caller
+ * (PyTorch's allocator) and borrowed for the call; only scratch is owned by the
+ * context.  Every launch goes to the explicit hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream).  Functions return 0 on success or a
+ * negative code, with the message in vae_last_error().  A context is not
+ * re-entrant; use one per process / GPU.
+ */
+#ifndef VAE_STEP_H
+#define VAE_STEP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vae_ctx vae_ctx;
+typedef void* vae_stream_t; /* hipStream_t */
+
+#define VAE_NUM_PARAMS 40 /* tensors of VanillaVAE.state_dict() that are parameters */
+#define VAE_NUM_BN 8
+#define VAE_DTYPE_F32 0  /* f32 storage, f32-input MFMA: exact f32 FMA-chain arithmetic */
+#define VAE_DTYPE_BF16 1 /* bf16 activation/weight storage, bf16 MFMA, f32 accumulate/statistics */
+
+const char* vae_last_error(void);
+int vae_abi_version(void);
+
+/* Flat parameter buffer layout.  Tensors appear in the reference's state_dict order
+ * (models.py:41-82): encoder.{0..3}.{0.weight,0.bias,1.weight,1.bias}, fc_mu.{weight,bias},
+ * fc_var.{weight,bias}, decoder_input.{weight,bias}, decoder.{0..2}.{...}, final_layer.{0.weight,
+ * 0.bias,1.weight,1.bias,3.weight,3.bias}; each keeps the reference's own element layout
+ * (Conv2d [Cout,Cin,3,3], ConvTranspose2d [Cin,Cout,3,3], Linear [out,in]).
+ * generalised=0: flattened_size = 1024 (models.py:33,36; img_size must be 32).
+ * generalised=1: flattened_size = 256*(img_size/16)^2 (not reference behaviour). */
+int vae_param_layout(int img_size, int latent_dim, int generalised, int64_t* offsets /*[40]*/,
+                     int64_t* sizes /*[40]*/, int64_t* total);
+/* BatchNorm running statistics: one f32 buffer, per layer running_mean[C] then running_var[C]. */
+int vae_bn_layout(int64_t* offsets /*[8]*/, int64_t* channels /*[8]*/, int64_t* total);
+
+/* Replaces VanillaVAE.__init__'s device state (models.py:10-83): allocates scratch for
+ * batches up to max_batch.  dtype: VAE_DTYPE_*. */
+vae_ctx* vae_create(int img_size, int latent_dim, int max_batch, int dtype, int generalised);
+void vae_destroy(vae_ctx* ctx);
+/* bytes of device scratch held by the context */
+int64_t vae_workspace_bytes(const vae_ctx* ctx);
+
+/* VanillaVAE.forward (models.py:185-188): encode (:107-145), reparameterize (:177-183),
+ * decode (:147-175); also accumulates the ELBO terms of VanillaVAE.loss (:208,:214) and the
+ * reconstruction gradient so that vae_loss / vae_backward need no second pass.
+ *   x [B,1,H,W] f32 in [0,1];  params: flat buffer (vae_param_layout)
+ *   bn_running / num_batches_tracked[8]: updated when train!=0 (momentum 0.1, unbiased var)
+ *   eps [B,L] f32: the torch.randn_like draw of models.py:182; NULL -> generated on device
+ *       from the counter-based normal generator (seed, stream 5) that oracle/ restates
+ *   train=0 uses running statistics (model.eval(), evaluation.py:42)
+ *   outputs: xhat [B,1,H,W], mu/log_var/z [B,L], all f32. */
+int vae_forward(vae_ctx* ctx, const float* x, int batch, const float* params, float* bn_running,
+                int64_t* num_batches_tracked, const float* eps, uint64_t seed, int train, float* xhat,
+                float* mu, float* log_var, float* z, vae_stream_t stream);
+
+/* EncoderOutput.pre_latents (models.py:133, types_helpers.py:20) of the last forward,
+ * [B, flattened_size] f32 in the reference's NCHW-flatten order. */
+int vae_pre_latents(vae_ctx* ctx, float* out, vae_stream_t stream);
+/* eps actually used by the last forward, [B,L]. */
+int vae_last_eps(vae_ctx* ctx, float* out, vae_stream_t stream);
+
+/* VanillaVAE.loss (models.py:190-225) for the last forward: out3 = {loss, reconstruction_loss,
+ * kld_loss} with kld_loss sign-flipped as at models.py:224. */
+int vae_loss(vae_ctx* ctx, float kld_weight, float* out3, vae_stream_t stream);
+
+/* VanillaVAE.loss (models.py:190-225) on arbitrary caller tensors: xhat/target [n], mu/log_var
+ * [B,L].  Optional outputs (NULL to skip): unscaled gradients of the loss w.r.t. xhat, mu, log_var
+ * (BCE grad (x-t)/max(x(1-x),1e-12)/n as ATen computes it). */
+int vae_elbo_generic(const float* xhat, const float* target, const float* mu, const float* log_var, int64_t n,
+                     int batch, int latent_dim, float kld_weight, float* out3, float* g_xhat, float* g_mu,
+                     float* g_log_var, vae_stream_t stream);
+
+/* loss.backward() (train.py:650) for the last train-mode forward.
+ *   grads: flat f32 buffer, same layout as params; every tensor is overwritten.
+ *   use_std: 1 adds the gradient of the standard ELBO of vae_loss (reconstruction term fused in
+ *           the forward, plus d(kld_weight*KL)/d(mu,log_var), models.py:208-216), scaled by
+ *   gscale: device scalar = upstream gradient of loss.backward(), NULL = 1.
+ *   g_xhat [B,1,H,W], g_mu/g_log_var/g_z [B,L], g_pre [B,F]: optional additional upstream
+ *           gradients on the ModelOutput tensors (NULL = none). */
+int vae_backward(vae_ctx* ctx, const float* x, const float* params, float* grads, const float* g_xhat,
+                 const float* gscale, const float* g_mu, const float* g_log_var, const float* g_z,
+                 const float* g_pre, float kld_weight, int use_std, vae_stream_t stream);
+
+/* torch.optim.AdamW.step (train.py:228,656) on up to two contiguous ranges of the flat
+ * buffers (the encoder and decoder groups of train.py:210-225), each with the lr and beta1
+ * OneCycleLR set for this step (train.py:233-238,659).  step is 1-based. */
+int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int ngroups,
+                   const int64_t* offsets, const int64_t* sizes, const float* lrs, const float* beta1s,
+                   float beta2, float eps, float weight_decay, float grad_scale, int step,
+                   vae_stream_t stream);
+
+/* One whole training step (train.py:634-659 minus logging): forward, loss, backward, AdamW. */
+int vae_train_step(vae_ctx* ctx, const float* x, int batch, float* params, float* grads, float* exp_avg,
+                   float* exp_avg_sq, float* bn_running, int64_t* num_batches_tracked, const float* eps,
+                   uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
+                   const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
+                   float weight_decay, int step, float* xhat, float* mu, float* log_var, float* z,
+                   float* out3, vae_stream_t stream);
+
+/* Synthetic pianoroll/line batch with the distribution of data_generators.py:45-77
+ * (called as at :97-104), seeded; x [B,1,H,H] f32 in {0,1}.  Device-side generator. */
+int vae_synth_pianoroll(float* x, int batch, int img_size, uint64_t seed, vae_stream_t stream);
+
+/* Debug / test hooks: copy an internal NHWC tensor to f32 NCHW.  which: 0..7 raw conv output
+ * of BN layer i, 8..15 its dz, 16 decoder_input output, 17 its gradient. */
+int vae_debug_tensor(vae_ctx* ctx, int which, float* out, int64_t capacity, vae_stream_t stream);
+/* hardware self-test of the transposed LDS read used by the bf16 weight-gradient kernel */
+int vae_selftest_tr16(vae_stream_t stream);
+/* 0/1: use ds_read_b64_tr_b16 in the bf16 weight-gradient kernel (default 1) */
+int vae_set_option(vae_ctx* ctx, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

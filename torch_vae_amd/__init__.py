@@ -1,0 +1,23 @@
+"""torch_vae_amd: MI355X-native (gfx950) VanillaVAE training step.
+
+Drop-in for the hot path of finlaymiller/torch-vae: ``models.VanillaVAE`` and
+``train.train_one_epoch`` with the same call surface, backed by hand-written HIP
+kernels behind a C ABI (include/vae_step.h).  Importing this package does not load
+the HIP library; the first call that needs it does, and fails loudly if it is missing.
+"""
+from .types_helpers import EncoderOutput, LossOutput, ModelOutput  # noqa: F401
+
+__all__ = ["VanillaVAE", "FusedAdamW", "train_one_epoch", "build_optimizer", "SyntheticPianorollLoader"]
+
+
+def __getattr__(name):
+    if name == "VanillaVAE":
+        from .models import VanillaVAE
+        return VanillaVAE
+    if name == "FusedAdamW":
+        from .optim import FusedAdamW
+        return FusedAdamW
+    if name in ("train_one_epoch", "build_optimizer", "SyntheticPianorollLoader", "allreduce_gradients"):
+        from . import train
+        return getattr(train, name)
+    raise AttributeError(name)

@@ -1,0 +1,111 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) VAE-step kernels.
+// Wavefront = 64 lanes; MFMA 32x32 tiles; all kernels use 256-thread workgroups.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __bf16 bf16;
+
+#define LDS_PTR(T) T __attribute__((address_space(3)))*
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ float tofloat(float v) { return v; }
+__device__ __forceinline__ float tofloat(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T fromfloat(float v);
+template <> __device__ __forceinline__ float fromfloat<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 fromfloat<bf16>(float v) { return (bf16)v; }
+
+// Round a value the way it will be stored (so statistics see the stored tensor).
+template <typename T> __device__ __forceinline__ float round_as(float v) { return tofloat(fromfloat<T>(v)); }
+
+// ---- 16-byte vector of storage elements -----------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> zero_vec16() {
+    Vec16<T> r;
+#pragma unroll
+    for (int i = 0; i < Vec16<T>::N; ++i) r.set(i, 0.f);
+    return r;
+}
+
+// ---- MFMA fragment: 8 k-values per lane, k = 8*(lane>>5) + j ---------------
+// bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight v_mfma_f32_32x32x2_f32, step j
+// contracting k in {j, 8+j}; the k permutation is the same for A and B, so the
+// product is exact f32 FMA-chain arithmetic over the same 16 k values.
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+    float v[8];
+    __device__ __forceinline__ void set(int j, float x) { v[j] = x; }
+};
+template <> struct Frag<bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16)x; }
+};
+
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+
+// 8 consecutive elements from a generic (global or LDS) pointer, 16-B aligned.
+__device__ __forceinline__ Frag<float> load_frag(const float* p) {
+    Frag<float> f;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+    return f;
+}
+__device__ __forceinline__ Frag<bf16> load_frag(const bf16* p) {
+    Frag<bf16> f;
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+    return f;
+}
+
+// accumulator element i of a 32x32 tile sits at row acc_row(i, lane), col lane&31
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// ---- per-channel affine (+leaky) transform applied while staging a tensor --
+//   v = leaky( t0 * p0[c] + t1 * p1[c] + p2[c], slope )
+// activation load : t0 = raw conv output y, p = (gamma*invstd, 0, beta - mean*gamma*invstd), slope 0.01
+// gradient load   : t0 = dz, t1 = y, p = BatchNorm-backward coefficients, slope 1
+__device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Per-layer statistics / coefficient block, C floats per row:
+//  0 sc   1 zero  2 sh   3 invstd  4 xm(=-mean*invstd)  5 p0  6 p1  7 p2  8 mean  9 var
+enum { LC_SC = 0, LC_ZERO = 1, LC_SH = 2, LC_INVSTD = 3, LC_XM = 4, LC_P0 = 5, LC_P1 = 6, LC_P2 = 7, LC_MEAN = 8, LC_VAR = 9, LC_ROWS = 10 };
+
+#define HIP_CHECK_RET(expr)                                                       \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) return vae_set_error(#expr, hipGetErrorString(_e)); \
+    } while (0)

@@ -1,0 +1,497 @@
+// Implicit-GEMM 3x3 stride-2 convolution kernels on MFMA for gfx950.
+//
+// Internal activation layout is NHWC ("channels-last"): the MFMA A operand needs
+// 8 consecutive k (= input channels) per lane, which NHWC gives as one 16-byte
+// access.  Four kernels cover every conv / transposed-conv of the VAE:
+//
+//   down_kernel  out[b,oy,ox,n] = sum_{ky,kx,k} f(in[b,2oy+ky-1,2ox+kx-1,k]) * Wp[ky*3+kx][k][n]
+//                = Conv2d(k3,s2,p1) forward          (models.py:45)   and
+//                = ConvTranspose2d input-gradient    (autograd of models.py:66-68,77)
+//   up_kernel    out[b,oy,ox,n] = sum_{ky,kx: (oy+1-ky),(ox+1-kx) even} f(in[b,(oy+1-ky)/2,(ox+1-kx)/2,k]) * Wp[..][k][n]
+//                = ConvTranspose2d(k3,s2,p1,op1) forward (models.py:66-68,77) and
+//                = Conv2d input-gradient
+//   wgrad_kernel dW[a][b][ky][kx] = sum_{img,y,x} fS(S[img,y,x,a]) * fG(G[img,2y+ky-1,2x+kx-1,b])
+//                = weight gradient of both layer kinds (S = low-res side, G = high-res side)
+//   dense_kernel C[m][n] = sum_k f(A[m][k]) * Bp[k][n]   (fc_mu|fc_var forward, decoder_input dgrad)
+//
+// f() is the per-channel affine+LeakyReLU load transform of common.cuh: the
+// producer's train-mode BatchNorm + LeakyReLU (forward operands) or the BatchNorm
+// backward (gradient operands) is applied while the tile is staged into LDS, so
+// neither the normalised activation nor dL/dy is ever materialised in HBM.
+// Epilogues emit the per-channel sums train-mode BatchNorm needs (H2 in SURVEY.md 7).
+#pragma once
+#include "common.cuh"
+
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_PLAIN = 2 };
+
+template <typename T> struct ConvArgs {
+    const T* src0; const T* src1; const float* coef; float slope;  // input + load transform (rows p0,p1,p2, stride Cin)
+    const T* wp; const float* bias;                                // packed [9][Cin/8][Cout][8]
+    T* out;
+    const T* yout; const float* ocoef; float oslope;               // EPI_BWD: output-side layer block (rows LC_*, stride Cout)
+    double* stat;                                                  // [2][Cout] (EPI_FWD: sum y, sum y^2; EPI_BWD: sum dz, sum dz*xhat)
+    int B, Hs, Ws, Cin, Cout;                                      // Hs,Ws: low-res side (down: output, up: input)
+    int lth, ltw, lTB, tiles_x, tiles_y;
+    int two_src, epi;                                              // runtime: gradient-operand load / epilogue kind
+};
+
+static constexpr int PATCH_PITCH = 80;  // bytes per staged pixel: 64 B of channels + 16 B pad (LDS bank spread)
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load_transform16(const T* s0, const T* s1, bool two, size_t g, const float* cf,
+                                                     int C, int cb, float slope) {
+    Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(s0 + g);
+    Vec16<T> o;
+    if (two) {
+        Vec16<T> v1 = *reinterpret_cast<const Vec16<T>*>(s1 + g);
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e)
+            o.set(e, leaky(v0.get(e) * cf[cb + e] + v1.get(e) * cf[C + cb + e] + cf[2 * C + cb + e], slope));
+    } else {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) o.set(e, leaky(v0.get(e) * cf[cb + e] + cf[2 * C + cb + e], slope));
+    }
+    return o;
+}
+
+// Common epilogue for one accumulator value.
+template <typename T>
+__device__ __forceinline__ void epi_store(const ConvArgs<T>& a, size_t idx, int n, float accv, float bv, float sc,
+                                          float sh, float is, float xm, float& s1, float& s2) {
+    const int EPI = a.epi;
+    if (EPI == EPI_FWD) {
+        float v = round_as<T>(accv + bv);
+        a.out[idx] = fromfloat<T>(v);
+        s1 += v; s2 += v * v;
+    } else if (EPI == EPI_BWD) {
+        float y = tofloat(a.yout[idx]);
+        float z = y * sc + sh;
+        float dz = round_as<T>(z > 0.f ? accv : accv * a.oslope);
+        a.out[idx] = fromfloat<T>(dz);
+        s1 += dz; s2 += dz * (y * is + xm);
+    } else {
+        a.out[idx] = fromfloat<T>(accv);
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
+    const bool TWO_SRC = a.two_src != 0; const int EPI = a.epi;
+    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
+    const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP;
+    const int Hin = 2 * a.Hs, Win = 2 * a.Ws, Cin = a.Cin, Cout = a.Cout;
+    float* cf = reinterpret_cast<float*>(smem);
+    char* patch = smem + ((3 * Cin * 4 + 15) & ~15);
+    float* red = reinterpret_cast<float*>(patch + npix * PATCH_PITCH);
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+    const int b0 = bt << a.lTB, oy0 = ty << a.lth, ox0 = tx << a.ltw, n0 = blockIdx.y * 32 * NT;
+
+    for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+
+    const int R = wave * 32 + r;
+    const int pbase = ((R >> (a.lth + a.ltw)) * PH + 2 * ((R >> a.ltw) & (th - 1))) * PW + 2 * (R & (tw - 1));
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();
+        for (int it = tid; it < npix * 4; it += 256) {
+            const int pix = it >> 2, q = it & 3;
+            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int b = b0 + img, iy = 2 * oy0 - 1 + py, ix = 2 * ox0 - 1 + px;
+            Vec16<T> v = zero_vec16<T>();
+            if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+                const size_t g = (((size_t)b * Hin + iy) * Win + ix) * Cin + c0 + q * E16;
+                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, g, cf, Cin, c0 + q * E16, a.slope);
+            }
+            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const T* ap = reinterpret_cast<const T*>(patch + (pbase + (t / 3) * PW + (t % 3)) * PATCH_PITCH + ks * 32) + h * 8;
+                Frag<T> af = load_frag(ap);
+                const size_t kg = (size_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    Frag<T> bf = load_frag(a.wp + (kg * Cout + n0 + nt * 32 + r) * 8);
+                    mma(acc[nt], af, bf);
+                }
+            }
+        }
+    }
+
+    // epilogue: lane = output channel (column), 16 accumulator rows = pixels
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + r;
+        float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f, s1 = 0.f, s2 = 0.f;
+        if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
+        if (EPI == EPI_BWD) {
+            sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
+            is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int RR = wave * 32 + acc_row(i, lane);
+            const int b = b0 + (RR >> (a.lth + a.ltw));
+            if (b < a.B) {
+                const int oy = oy0 + ((RR >> a.ltw) & (th - 1)), ox = ox0 + (RR & (tw - 1));
+                const size_t idx = (((size_t)b * a.Hs + oy) * a.Ws + ox) * Cout + n;
+                epi_store<T>(a, idx, n, acc[nt][i], bv, sc, sh, is, xm, s1, s2);
+            }
+        }
+        if (EPI != EPI_PLAIN) {
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) { red[((wave * NT + nt) * 32 + r) * 2] = s1; red[((wave * NT + nt) * 32 + r) * 2 + 1] = s2; }
+        }
+    }
+    if (EPI != EPI_PLAIN) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[((w * NT) * 32 + tid) * 2]; s2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
+            unsafeAtomicAdd(&a.stat[n0 + tid], (double)s1);
+            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)s2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
+    const bool TWO_SRC = a.two_src != 0; const int EPI = a.epi;
+    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
+    const int PH = th + 1, PW = tw + 1, PP = PH * PW, npix = TB * PP;
+    const int Hs = a.Hs, Ws = a.Ws, Cin = a.Cin, Cout = a.Cout;
+    float* cf = reinterpret_cast<float*>(smem);
+    char* patch = smem + ((3 * Cin * 4 + 15) & ~15);
+    float* red = reinterpret_cast<float*>(patch + npix * PATCH_PITCH);
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+    const int b0 = bt << a.lTB, iy0 = ty << a.lth, ix0 = tx << a.ltw, n0 = blockIdx.y * 32 * NT;
+
+    for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+
+    const int R = wave * 32 + r;
+    const int pbase = ((R >> (a.lth + a.ltw)) * PH + ((R >> a.ltw) & (th - 1))) * PW + (R & (tw - 1));
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][nt][i] = 0.f;
+
+    // (class, tap, input offset) table: out(2i+py,2j+px) <- in(i+di,j+dj) * W[tap]
+    constexpr int NTAP = 9;
+    constexpr int tap_cls[NTAP] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    constexpr int tap_t[NTAP] = {4, 5, 3, 7, 1, 8, 6, 2, 0};
+    constexpr int tap_off[NTAP] = {0, 0, 1, 0, 2, 0, 1, 2, 3};  // di*2+dj
+
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();
+        for (int it = tid; it < npix * 4; it += 256) {
+            const int pix = it >> 2, q = it & 3;
+            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int b = b0 + img, iy = iy0 + py, ix = ix0 + px;
+            Vec16<T> v = zero_vec16<T>();
+            if (b < a.B && iy < Hs && ix < Ws) {
+                const size_t g = (((size_t)b * Hs + iy) * Ws + ix) * Cin + c0 + q * E16;
+                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, g, cf, Cin, c0 + q * E16, a.slope);
+            }
+            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag<T> af[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                af[o] = load_frag(reinterpret_cast<const T*>(patch + (pbase + (o >> 1) * PW + (o & 1)) * PATCH_PITCH + ks * 32) + h * 8);
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) {
+                const size_t kg = (size_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    Frag<T> bf = load_frag(a.wp + (kg * Cout + n0 + nt * 32 + r) * 8);
+                    mma(acc[tap_cls[k]][nt], af[tap_off[k]], bf);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + r;
+        float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f, s1 = 0.f, s2 = 0.f;
+        if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
+        if (EPI == EPI_BWD) {
+            sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
+            is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int RR = wave * 32 + acc_row(i, lane);
+                const int b = b0 + (RR >> (a.lth + a.ltw));
+                if (b < a.B) {
+                    const int oy = 2 * (iy0 + ((RR >> a.ltw) & (th - 1))) + (c >> 1);
+                    const int ox = 2 * (ix0 + (RR & (tw - 1))) + (c & 1);
+                    const size_t idx = (((size_t)b * 2 * Hs + oy) * 2 * Ws + ox) * Cout + n;
+                    epi_store<T>(a, idx, n, acc[c][nt][i], bv, sc, sh, is, xm, s1, s2);
+                }
+            }
+        }
+        if (EPI != EPI_PLAIN) {
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) { red[((wave * NT + nt) * 32 + r) * 2] = s1; red[((wave * NT + nt) * 32 + r) * 2 + 1] = s2; }
+        }
+    }
+    if (EPI != EPI_PLAIN) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[((w * NT) * 32 + tid) * 2]; s2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
+            unsafeAtomicAdd(&a.stat[n0 + tid], (double)s1);
+            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)s2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient.  K of the GEMM = low-res pixels; both operands are staged in
+// LDS as [pixel][channel] and read k-major: bf16 through ds_read_b64_tr_b16 (the
+// hardware transpose read), f32 as one dword per k (the 32x32x2 f32 MFMA takes a
+// single k per lane, so no transpose is needed).
+template <typename T> struct WgradArgs {
+    const T* s0; const T* s1; const float* scoef; float sslope;  // low-res operand  [B,Hs,Ws,CA]
+    const T* g0; const T* g1; const float* gcoef; float gslope;  // high-res operand [B,2Hs,2Ws,CB]
+    float* slab;                                                 // [nsplit*WK][9][CA][CB]
+    int s_two, g_two;
+    int B, Hs, Ws, CA, CB;
+    int lth, ltw, lTB, tiles_x, tiles_y, n_tiles, tiles_per_split;
+    int use_tr16;
+};
+
+static constexpr int WG_KP = 64;  // low-res pixels per K tile
+
+template <typename T, int WA, int WB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
+    const bool S_TWO = a.s_two != 0, G_TWO = a.g_two != 0;
+    constexpr int WK = 4 / (WA * WB), E16 = 16 / sizeof(T);
+    constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
+    constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
+    constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
+    const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP;
+    const int Hs = a.Hs, Ws = a.Ws, Hg = 2 * a.Hs, Wg = 2 * a.Ws, CA = a.CA, CB = a.CB;
+    const int a0 = blockIdx.y * 32 * WA, bc0 = blockIdx.z * 32 * WB;
+    const int wa = wave % WA, wb = (wave / WA) % WB, wk = wave / (WA * WB);
+
+    float* cfs = reinterpret_cast<float*>(smem);             // [3][32*WA]
+    float* cfg = cfs + 3 * 32 * WA;                          // [3][32*WB]
+    char* stile = reinterpret_cast<char*>(cfg + 3 * 32 * WB);  // [64][SPITCH]
+    char* gtile = stile + WG_KP * SPITCH;                    // [npix][GPITCH]
+
+    for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
+    for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // lane geometry for k-major reads
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+
+    const int t_begin = blockIdx.x * a.tiles_per_split;
+    const int t_end = min(a.n_tiles, t_begin + a.tiles_per_split);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+        const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
+        __syncthreads();
+        for (int it = tid; it < WG_KP * SCH; it += 256) {
+            const int k = it / SCH, qq = it - k * SCH;
+            const int b = b0 + (k >> (a.lth + a.ltw)), y = y0 + ((k >> a.ltw) & (th - 1)), x = x0 + (k & (tw - 1));
+            Vec16<T> v = zero_vec16<T>();
+            if (b < a.B) {
+                const size_t g = (((size_t)b * Hs + y) * Ws + x) * CA + a0 + qq * E16;
+                v = load_transform16<T>(a.s0, a.s1, S_TWO, g, cfs, 32 * WA, qq * E16, a.sslope);
+                // note: coefficient rows are stored tile-local (stride 32*WA), channel index qq*E16
+            }
+            *reinterpret_cast<Vec16<T>*>(stile + k * SPITCH + qq * 16) = v;
+        }
+        for (int it = tid; it < npix * GCH; it += 256) {
+            const int pix = it / GCH, qq = it - pix * GCH;
+            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int b = b0 + img, iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+            Vec16<T> v = zero_vec16<T>();
+            if (b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg) {
+                const size_t g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
+                v = load_transform16<T>(a.g0, a.g1, G_TWO, g, cfg, 32 * WB, qq * E16, a.gslope);
+            }
+            *reinterpret_cast<Vec16<T>*>(gtile + pix * GPITCH + qq * 16) = v;
+        }
+        __syncthreads();
+
+        for (int ks = wk; ks < WG_KP / 16; ks += WK) {
+            Frag<T> af;
+            int growbase[8];  // patch pixel index (tap 0,0) of the 8 k rows this lane touches
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + 8 * h + j;
+                    af.v[j] = *reinterpret_cast<const float*>(stile + k * SPITCH + (wa * 32 + r) * 4);
+                    growbase[j] = ((k >> (a.lth + a.ltw)) * PH + 2 * ((k >> a.ltw) & (th - 1))) * PW + 2 * (k & (tw - 1));
+                }
+            } else {
+                if (a.use_tr16) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int k = ks * 16 + 8 * (g4 >> 1) + 4 * half + q;
+                        const char* ad = stile + k * SPITCH + (wa * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) af.v[4 * half + e] = __builtin_bit_cast(bf16, v[e]);
+                        growbase[half] = ((k >> (a.lth + a.ltw)) * PH + 2 * ((k >> a.ltw) & (th - 1))) * PW + 2 * (k & (tw - 1));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = ks * 16 + 8 * h + j;
+                        af.v[j] = *reinterpret_cast<const bf16*>(stile + k * SPITCH + (wa * 32 + r) * 2);
+                        growbase[j] = ((k >> (a.lth + a.ltw)) * PH + 2 * ((k >> a.ltw) & (th - 1))) * PW + 2 * (k & (tw - 1));
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = (t / 3) * PW + (t % 3);
+                Frag<T> bf;
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        bf.v[j] = *reinterpret_cast<const float*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 4);
+                } else {
+                    if (a.use_tr16) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const char* ad = gtile + (growbase[half] + toff) * GPITCH + (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) bf.v[4 * half + e] = __builtin_bit_cast(bf16, v[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            bf.v[j] = *reinterpret_cast<const bf16*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 2);
+                    }
+                }
+                mma(acc[t], af, bf);
+            }
+        }
+    }
+
+    // partial slab: rows = low-res-side channel (a), lanes = high-res-side channel (b)
+    const size_t slab_id = (size_t)blockIdx.x * WK + wk;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ca = a0 + wa * 32 + acc_row(i, lane), cb = bc0 + wb * 32 + r;
+            a.slab[((slab_id * 9 + t) * CA + ca) * CB + cb] = acc[t][i];
+        }
+    }
+}
+
+// out[(a*CB+b)*9+t] = sum_s slab[s][t][a][b]   (CA>0: conv weight layout [A][B][3][3])
+// out[j]            = sum_s slab[s][j]          (CA==0)
+__global__ void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out, int CA, int CB) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + j];
+    if (CA > 0) {
+        const int t = j / (CA * CB), rem = j - t * CA * CB;
+        out[(size_t)rem * 9 + t] = s;
+    } else {
+        out[j] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T> struct DenseArgs {
+    const T* A; const float* coef; float slope; int C;  // transform channel = k & (C-1); coef==nullptr -> identity
+    const T* Bp;                                        // packed [K/8][Npad][8]
+    float* slab;                                        // [nsplit][M][Npad]
+    int M, K, Npad, ksteps_per_split;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs<T> a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int m = blockIdx.x * 128 + wave * 32 + r, n0 = blockIdx.z * 32 * NT;
+    const int ks0 = blockIdx.y * a.ksteps_per_split, ks1 = min(a.K / 16, ks0 + a.ksteps_per_split);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int k = ks * 16 + 8 * h;
+        Frag<T> af;
+        if (m < a.M) {
+            Frag<T> raw = load_frag(a.A + (size_t)m * a.K + k);
+            if (a.coef) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = (k + j) & (a.C - 1);
+                    float v;
+                    if constexpr (sizeof(T) == 4) v = raw.v[j]; else v = (float)raw.v[j];
+                    af.set(j, leaky(v * a.coef[c] + a.coef[2 * a.C + c], a.slope));
+                }
+            } else {
+                af = raw;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af.set(j, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            Frag<T> bf = load_frag(a.Bp + ((size_t)(k >> 3) * a.Npad + n0 + nt * 32 + r) * 8);
+            mma(acc[nt], af, bf);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int mm = blockIdx.x * 128 + wave * 32 + acc_row(i, lane);
+            if (mm < a.M) a.slab[((size_t)blockIdx.y * a.M + mm) * a.Npad + n0 + nt * 32 + r] = acc[nt][i];
+        }
+}

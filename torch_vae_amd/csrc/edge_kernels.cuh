@@ -1,0 +1,697 @@
+// Non-GEMM-shaped kernels of the VAE step for gfx950: the 1-channel ends of the
+// network (HBM streams), the latent block, BatchNorm finalisation, weight packing
+// and the fused AdamW update.  All reductions: registers -> wave shuffles -> LDS
+// -> one double-precision atomic per channel per workgroup.
+#pragma once
+#include "common.cuh"
+
+// reduce v across the lanes that share (lane & 3): offsets 4..32
+__device__ __forceinline__ float cg_sum(float v) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* o) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float* o) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* o);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* o) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = o[i]; b[i] = o[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float* o) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)o[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+// ---------------------------------------------------------------------------
+// encoder block 0: Conv2d(1->32,k3,s2,p1) forward (models.py:45 with in_channels=1).
+// x [B,H,W] f32 -> y [B,H/2,W/2,32] T, plus sum / sum-of-squares per channel.
+// thread = (pixel slot, 8-channel group); a pixel's 32 channels are 4 adjacent lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y,
+                                                        double* __restrict__ stat, int B, int H, int W) {
+    __shared__ float red[4][4][16];
+    const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long P = (long)B * Ho * Wo;
+    float wr[8][9], br[8], s1[8], s2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        br[c] = bias[cg * 8 + c]; s1[c] = 0.f; s2[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(cg * 8 + c) * 9 + t];
+    }
+    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
+        const int ox = p % Wo, oy = (p / Wo) % Ho; const long b = p / ((long)Wo * Ho);
+        float xv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+            xv[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(b * H + iy) * W + ix] : 0.f;
+        }
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float acc = br[c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += wr[c][t] * xv[t];
+            o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
+        }
+        store8<T>(y + p * 32 + cg * 8, o);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        s1[c] = cg_sum(s1[c]); s2[c] = cg_sum(s2[c]);
+        if (lane < 4) { red[wave][lane][c] = s1[c]; red[wave][lane][8 + c] = s2[c]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int ch = tid & 31, k = tid >> 5;  // k=0: sum, k=1: sumsq
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += red[wv][ch >> 3][k * 8 + (ch & 7)];
+        unsafeAtomicAdd(&stat[k * 32 + ch], (double)s);
+    }
+}
+
+// encoder block 0 weight gradient: dW[co][t] = sum_p G[p][co] * x[p (+) t], G = dz*p0 + y*p1 + p2
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dz,
+                                                          const T* __restrict__ y, const float* __restrict__ gcoef,
+                                                          float* __restrict__ slab, int B, int H, int W) {
+    __shared__ float red[4][4][72];
+    const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long P = (long)B * Ho * Wo;
+    float p0[8], p1[8], p2[8], acc[8][9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        p0[c] = gcoef[cg * 8 + c]; p1[c] = gcoef[32 + cg * 8 + c]; p2[c] = gcoef[64 + cg * 8 + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    }
+    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
+        const int ox = p % Wo, oy = (p / Wo) % Ho; const long b = p / ((long)Wo * Ho);
+        float xv[9], dv[8], yv[8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+            xv[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(b * H + iy) * W + ix] : 0.f;
+        }
+        load8<T>(dz + p * 32 + cg * 8, dv); load8<T>(y + p * 32 + cg * 8, yv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float g = dv[c] * p0[c] + yv[c] * p1[c] + p2[c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][t] += g * xv[t];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float s = cg_sum(acc[c][t]);
+            if (lane < 4) red[wave][lane][c * 9 + t] = s;
+        }
+    __syncthreads();
+    for (int j = tid; j < 288; j += 256) {
+        const int t = j / 32, co = j % 32;  // slab layout [t][co] (CA=32, CB=1)
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += red[wv][co >> 3][(co & 7) * 9 + t];
+        slab[(size_t)blockIdx.x * 288 + j] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// final_layer tail: BN+LeakyReLU (on load) -> Conv2d(32->1,k3,s1,p1) -> Sigmoid  (models.py:78-81)
+// fused with the reconstruction term of the ELBO (models.py:208) and its gradient:
+//   xhat = sigmoid(logit);  bce += -(t*max(log xhat,-100) + (1-t)*max(log(1-xhat),-100))
+//   dlogit = (xhat-t)/max(xhat(1-xhat),1e-12) * xhat(1-xhat) / N          (ATen BCE + sigmoid backward)
+// Tile: 32x16 outputs per workgroup; phase 1 computes per input pixel the nine
+// 32-channel dot products, phase 2 gathers the 3x3 neighbourhood from LDS.
+struct ConvOutArgs {
+    const void* yf; const float* coef;      // [B,H,W,32] T, rows sc,0,sh
+    const float* wt; const float* bias;     // wt [9][32] (tap-major copy of final_layer.3.weight)
+    const float* target;                    // [B,H,W] (= the input x)
+    float* xhat; float* dlogit;             // [B,H,W]
+    double* accum;                          // [0] bce sum
+    int B, H, W; float inv_n; float slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void convout_fwd_kernel(ConvOutArgs a) {
+    constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2, NP = PH * PW;
+    __shared__ float part[NP * 9];
+    __shared__ float wred[4];
+    const int tid = threadIdx.x;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const int tile = blockIdx.x, tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const T* yf = reinterpret_cast<const T*>(a.yf);
+    for (int pix = tid; pix < NP; pix += 256) {
+        const int py = pix / PW, px = pix - py * PW, gy = y0 + py - 1, gx = x0 + px - 1;
+        float acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const T* src = yf + (((size_t)b * a.H + gy) * a.W + gx) * 32;
+#pragma unroll
+            for (int cgp = 0; cgp < 4; ++cgp) {
+                float v[8];
+                load8<T>(src + cgp * 8, v);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int ch = cgp * 8 + c;
+                    const float av = leaky(v[c] * a.coef[ch] + a.coef[64 + ch], a.slope);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[t] += av * a.wt[t * 32 + ch];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) part[pix * 9 + t] = acc[t];
+    }
+    __syncthreads();
+    float bsum = 0.f;
+    const float bo = a.bias[0];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int o = tid + k * 256, oy = o / TW, ox = o % TW;
+        float logit = bo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) logit += part[((oy + t / 3) * PW + ox + t % 3) * 9 + t];
+        const size_t gi = ((size_t)b * a.H + y0 + oy) * a.W + x0 + ox;
+        const float tg = a.target[gi];
+        const float xh = 1.f / (1.f + expf(-logit));
+        const float l1 = fmaxf(logf(xh), -100.f), l0 = fmaxf(logf(1.f - xh), -100.f);
+        bsum += -(tg * l1 + (1.f - tg) * l0);
+        const float om = xh * (1.f - xh);
+        a.xhat[gi] = xh;
+        a.dlogit[gi] = (xh - tg) / fmaxf(om, 1e-12f) * om * a.inv_n;
+    }
+    bsum = wave_sum(bsum);
+    if ((tid & 63) == 0) wred[tid >> 6] = bsum;
+    __syncthreads();
+    if (tid == 0) unsafeAtomicAdd(&a.accum[0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+}
+
+// dlogit = g_xhat * xhat*(1-xhat) [+ gscale * dlogit_std]: caller-supplied dL/dxhat, optionally on top
+// of the fused standard-ELBO gradient
+__global__ void dlogit_combine_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+                                      const float* __restrict__ dstd, const float* __restrict__ gscale,
+                                      float* __restrict__ dlogit, long n) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (g) { const float xh = xhat[i]; v = g[i] * xh * (1.f - xh); }
+        if (dstd) v += gs * dstd[i];
+        dlogit[i] = v;
+    }
+}
+
+// generic F.binary_cross_entropy(mean) forward + grad w.r.t. the prediction
+__global__ void bce_kernel(const float* __restrict__ xh_, const float* __restrict__ tg_, float* __restrict__ gx,
+                           double* __restrict__ accum, long n, float inv_n) {
+    __shared__ float wred[4];
+    float bsum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float xh = xh_[i], tg = tg_[i];
+        bsum += -(tg * fmaxf(logf(xh), -100.f) + (1.f - tg) * fmaxf(logf(1.f - xh), -100.f));
+        if (gx) gx[i] = (xh - tg) / fmaxf(xh * (1.f - xh), 1e-12f) * inv_n;
+    }
+    bsum = wave_sum(bsum);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&accum[0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+}
+
+// Backward of the output conv fused with the BN/LeakyReLU backward prologue of final_layer:
+//   dA[p][c] = sum_t w[t][c] dl[p - off(t)];  dz = dA * leaky'(z);  dW[c][t] += a[p][c] * dl[p - off(t)]
+//   stats: sum dz, sum dz*xhat_bn per channel; sum dl -> bias gradient.
+struct ConvOutBwdArgs {
+    const void* yf; const float* ocoef;   // layer block rows (stride 32)
+    const float* wt; const float* dlogit; const float* gscale;
+    void* dz; float* slab;                // slab [nWG][288] in [t][c] order
+    double* stat;                         // [2][32]
+    double* dbias;                        // sum of dlogit
+    int B, H, W; float slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
+    __shared__ float red[4][4][89];
+    const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
+    const long P = (long)a.B * a.H * a.W;
+    const T* yf = reinterpret_cast<const T*>(a.yf);
+    T* dzp = reinterpret_cast<T*>(a.dz);
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    float sc[8], sh[8], is[8], xm[8], wr[8][9], dw[8][9], s1[8], s2[8], sdl = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cg * 8 + c;
+        sc[c] = a.ocoef[LC_SC * 32 + ch]; sh[c] = a.ocoef[LC_SH * 32 + ch];
+        is[c] = a.ocoef[LC_INVSTD * 32 + ch]; xm[c] = a.ocoef[LC_XM * 32 + ch];
+        s1[c] = 0.f; s2[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { wr[c][t] = a.wt[t * 32 + ch]; dw[c][t] = 0.f; }
+    }
+    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
+        const int x = p % a.W, y = (p / a.W) % a.H; const long b = p / ((long)a.W * a.H);
+        float dl[9], yv[8], o[8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int qy = y - (t / 3) + 1, qx = x - (t % 3) + 1;
+            dl[t] = (qy >= 0 && qy < a.H && qx >= 0 && qx < a.W) ? a.dlogit[(b * a.H + qy) * a.W + qx] * gs : 0.f;
+        }
+        if (cg == 0) sdl += dl[4];
+        load8<T>(yf + p * 32 + cg * 8, yv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float z = yv[c] * sc[c] + sh[c];
+            const float av = leaky(z, a.slope);
+            float da = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { da += wr[c][t] * dl[t]; dw[c][t] += av * dl[t]; }
+            const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
+            o[c] = dzv; s1[c] += dzv; s2[c] += dzv * (yv[c] * is[c] + xm[c]);
+        }
+        store8<T>(dzp + p * 32 + cg * 8, o);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { const float s = cg_sum(dw[c][t]); if (lane < 4) red[wave][lane][c * 9 + t] = s; }
+        const float a1 = cg_sum(s1[c]), a2 = cg_sum(s2[c]);
+        if (lane < 4) { red[wave][lane][72 + c] = a1; red[wave][lane][80 + c] = a2; }
+    }
+    sdl = cg_sum(sdl);
+    if (lane == 0) red[wave][0][88] = sdl;
+    __syncthreads();
+    for (int j = tid; j < 288; j += 256) {
+        const int t = j / 32, ch = j % 32;
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += red[wv][ch >> 3][(ch & 7) * 9 + t];
+        a.slab[(size_t)blockIdx.x * 288 + j] = s;
+    }
+    if (tid < 64) {
+        const int ch = tid & 31, k = tid >> 5;
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += red[wv][ch >> 3][72 + k * 8 + (ch & 7)];
+        unsafeAtomicAdd(&a.stat[k * 32 + ch], (double)s);
+    }
+    if (tid == 64) unsafeAtomicAdd(a.dbias, (double)(red[0][0][88] + red[1][0][88] + red[2][0][88] + red[3][0][88]));
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm2d train-mode finalisation (models.py:46,69,78): batch statistics ->
+// load-transform coefficients; running stats with momentum 0.1 and unbiased variance.
+struct BnFwdArgs {
+    const double* stat; const float* gamma; const float* beta; float* block;  // block rows LC_*, stride C
+    float* running_mean; float* running_var; long long* nbt;
+    int C; double count; float eps, momentum; int update_running;
+};
+__global__ void bn_fwd_finalize_kernel(BnFwdArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && a.update_running && a.nbt) a.nbt[0] += 1;
+    if (c >= a.C) return;
+    const double mean = a.stat[c] / a.count;
+    double var = a.stat[a.C + c] / a.count - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double sc = (double)a.gamma[c] * invstd;
+    a.block[LC_SC * a.C + c] = (float)sc;
+    a.block[LC_ZERO * a.C + c] = 0.f;
+    a.block[LC_SH * a.C + c] = (float)((double)a.beta[c] - mean * sc);
+    a.block[LC_INVSTD * a.C + c] = (float)invstd;
+    a.block[LC_XM * a.C + c] = (float)(-mean * invstd);
+    a.block[LC_MEAN * a.C + c] = (float)mean;
+    a.block[LC_VAR * a.C + c] = (float)var;
+    if (a.update_running) {
+        const double unb = a.count > 1 ? var * a.count / (a.count - 1) : var;
+        a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mean);
+        a.running_var[c] = (float)((1.0 - a.momentum) * a.running_var[c] + a.momentum * unb);
+    }
+}
+// eval-mode coefficients from running statistics (evaluation path / model.eval())
+__global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float* block, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double invstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+    const double sc = (double)gamma[c] * invstd;
+    block[LC_SC * C + c] = (float)sc; block[LC_ZERO * C + c] = 0.f;
+    block[LC_SH * C + c] = (float)((double)beta[c] - (double)rm[c] * sc);
+    block[LC_INVSTD * C + c] = (float)invstd; block[LC_XM * C + c] = (float)(-(double)rm[c] * invstd);
+    block[LC_MEAN * C + c] = rm[c]; block[LC_VAR * C + c] = rv[c];
+}
+// backward: dgamma = sum dz*xhat, dbeta = sum dz; coefficients of dL/dy = dz*p0 + y*p1 + p2.
+// The conv bias feeding this BatchNorm has an analytically zero gradient (the batch mean removes it).
+struct BnBwdArgs {
+    const double* stat; const float* gamma; float* block; float* dgamma; float* dbeta; float* dconv_bias;
+    int C; double count;
+};
+__global__ void bn_bwd_finalize_kernel(BnBwdArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const double sdz = a.stat[c], sdzx = a.stat[a.C + c];
+    const double invstd = a.block[LC_INVSTD * a.C + c], mean = a.block[LC_MEAN * a.C + c];
+    const double s = (double)a.gamma[c] * invstd, m1 = sdz / a.count, m2 = sdzx / a.count;
+    a.block[LC_P0 * a.C + c] = (float)s;
+    a.block[LC_P1 * a.C + c] = (float)(-s * m2 * invstd);
+    a.block[LC_P2 * a.C + c] = (float)(-s * m1 + s * m2 * mean * invstd);
+    a.dgamma[c] = (float)sdzx; a.dbeta[c] = (float)sdz;
+    if (a.dconv_bias) a.dconv_bias[c] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// latent block.  fc_mu | fc_var partial products arrive as split-K slabs.
+struct LatentFwdArgs {
+    const float* slab; int nslab, npad;             // [nslab][B][npad]
+    const float* bmu; const float* bvar; const float* eps;
+    float* mu; float* lv; float* z; double* accum;  // accum[1] += sum(1 + lv - mu^2 - exp(lv))
+    int B, L;
+};
+__global__ void latent_fwd_kernel(LatentFwdArgs a) {
+    __shared__ float wred[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (i < a.B * a.L) {
+        const int b = i / a.L, l = i % a.L;
+        float m = a.bmu[l], v = a.bvar[l];
+        for (int s = 0; s < a.nslab; ++s) {
+            m += a.slab[((size_t)s * a.B + b) * a.npad + l];
+            v += a.slab[((size_t)s * a.B + b) * a.npad + a.L + l];
+        }
+        const float sd = expf(0.5f * v);                      // models.py:181
+        a.mu[i] = m; a.lv[i] = v; a.z[i] = a.eps[i] * sd + m;  // models.py:183
+        term = 1.f + v - m * m - expf(v);                     // models.py:214
+    }
+    term = wave_sum(term);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&a.accum[1], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+}
+
+// ELBO scalars (models.py:216-225): loss = bce + kld_weight*kld ; kld_loss reported with flipped sign.
+__global__ void loss_finalize_kernel(const double* accum, float* out3, double inv_n, double inv_b, float kld_weight) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double bce = accum[0] * inv_n, kld = -0.5 * accum[1] * inv_b;
+        out3[0] = (float)(bce + (double)kld_weight * kld); out3[1] = (float)bce; out3[2] = (float)(-kld);
+    }
+}
+__global__ void kld_only_kernel(const float* mu, const float* lv, double* accum, int n, float k, float* gmu, float* glv) {
+    __shared__ float wred[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (i < n) {
+        const float m = mu[i], v = lv[i], ev = expf(v);
+        term = 1.f + v - m * m - ev;
+        if (gmu) gmu[i] = k * m;                  // d(kld_weight*KL)/dmu
+        if (glv) glv[i] = k * 0.5f * (ev - 1.f);  // d(kld_weight*KL)/dlog_var
+    }
+    term = wave_sum(term);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&accum[1], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+}
+
+struct LatentBwdArgs {
+    const float* slab; int nslab, npad;   // dz_lat partials [nslab][B][npad]
+    const float* mu; const float* lv; const float* eps; const float* gscale;
+    const float* gmu; const float* glv; const float* gz;   // optional external grads [B,L]
+    float* dlat;                          // [B][2L]: dmu | dlv
+    int B, L; float kld_weight; int add_kl;
+};
+__global__ void latent_bwd_kernel(LatentBwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.L) return;
+    const int b = i / a.L, l = i % a.L;
+    float d = a.gz ? a.gz[i] : 0.f;
+    for (int s = 0; s < a.nslab; ++s) d += a.slab[((size_t)s * a.B + b) * a.npad + l];
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const float m = a.mu[i], v = a.lv[i], sd = expf(0.5f * v);
+    float dmu = d, dlv = d * a.eps[i] * sd * 0.5f;
+    if (a.add_kl) {
+        const float k = gs * a.kld_weight / (float)a.B;
+        dmu += k * m; dlv += k * 0.5f * (expf(v) - 1.f);
+    }
+    if (a.gmu) dmu += a.gmu[i];
+    if (a.glv) dlv += a.glv[i];
+    a.dlat[(size_t)b * 2 * a.L + l] = dmu; a.dlat[(size_t)b * 2 * a.L + a.L + l] = dlv;
+}
+// column sums of dlat -> fc_mu.bias / fc_var.bias gradients
+__global__ void colsum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ o0, float* __restrict__ o1, int split) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += m[(size_t)r * cols + j];
+    if (j < split) o0[j] = s; else o1[j - split] = s;
+}
+
+// f' (NHWC flatten: pix*256 + c) -> reference flatten index c*s2 + pix (models.py:133)
+__device__ __forceinline__ int fref_of(int fp, int s2) { return (fp & 255) * s2 + (fp >> 8); }
+
+// pre_latents in the reference's NCHW-flatten order (types_helpers.py:20), on request only.
+template <typename T>
+__global__ void pre_latents_kernel(const T* __restrict__ y, const float* __restrict__ coef, float slope,
+                                   float* __restrict__ out, int B, int F, int s2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * F) return;
+    const int fp = i % F; const long b = i / F; const int c = fp & 255;
+    out[b * F + fref_of(fp, s2)] = leaky(tofloat(y[i]) * coef[c] + coef[512 + c], slope);
+}
+
+// da4 = dlat @ [Wmu;Wvar], then LeakyReLU/BN prologue of encoder block 3 backward.
+template <typename T> struct FcDgradArgs {
+    const float* dlat; const T* wp; int npad;   // dlat [B][2L]; wp packed [F/8][npad][8]
+    const T* y; const float* ocoef; float slope;
+    const float* gpre;                          // optional external grad on pre_latents [B,F] (reference order)
+    T* dz; double* stat; int B, F, L2, s2;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
+    constexpr int BT = 16;
+    extern __shared__ __attribute__((aligned(16))) float dl_s[];  // [L2][BT]
+    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, b0 = blockIdx.y * BT;
+    for (int i = tid; i < a.L2 * BT; i += 256) {
+        const int j = i / BT, bb = i % BT;
+        dl_s[i] = (b0 + bb < a.B) ? a.dlat[(size_t)(b0 + bb) * a.L2 + j] : 0.f;
+    }
+    __syncthreads();
+    float acc[BT];
+#pragma unroll
+    for (int bb = 0; bb < BT; ++bb) acc[bb] = 0.f;
+    const T* wrow = a.wp + ((size_t)(fp >> 3) * a.npad) * 8 + (fp & 7);
+    for (int j = 0; j < a.L2; ++j) {
+        const float w = tofloat(wrow[(size_t)j * 8]);
+#pragma unroll
+        for (int q = 0; q < BT / 4; ++q) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[j * BT + q * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * w;
+        }
+    }
+    const int c = fp & 255;
+    const float sc = a.ocoef[LC_SC * 256 + c], sh = a.ocoef[LC_SH * 256 + c];
+    const float is = a.ocoef[LC_INVSTD * 256 + c], xm = a.ocoef[LC_XM * 256 + c];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < BT; ++bb) {
+        const int b = b0 + bb;
+        if (b < a.B) {
+            const size_t idx = (size_t)b * a.F + fp;
+            float da = acc[bb];
+            if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(fp, a.s2)];
+            const float yv = tofloat(a.y[idx]), z = yv * sc + sh;
+            const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
+            a.dz[idx] = fromfloat<T>(dzv);
+            s1 += dzv; s2 += dzv * (yv * is + xm);
+        }
+    }
+    unsafeAtomicAdd(&a.stat[c], (double)s1);
+    unsafeAtomicAdd(&a.stat[256 + c], (double)s2);
+}
+
+// dW_mu / dW_var [L][F_ref] = dlat^T @ a4  (K = batch)
+template <typename T> struct FcWgradArgs {
+    const float* dlat; const T* y; const float* coef; float slope;
+    float* dwmu; float* dwvar; int B, F, L, s2;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
+    constexpr int JT = 32, BC = 64;
+    __shared__ __attribute__((aligned(16))) float dl_s[BC * JT];
+    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, j0 = blockIdx.y * JT, L2 = 2 * a.L;
+    const int c = fp & 255;
+    const float sc = a.coef[c], sh = a.coef[512 + c];
+    float acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = 0.f;
+    for (int bc = 0; bc < a.B; bc += BC) {
+        __syncthreads();
+        for (int i = tid; i < BC * JT; i += 256) {
+            const int bb = i / JT, j = i % JT;
+            dl_s[i] = (bc + bb < a.B && j0 + j < L2) ? a.dlat[(size_t)(bc + bb) * L2 + j0 + j] : 0.f;
+        }
+        __syncthreads();
+        const int nb = min(BC, a.B - bc);
+        for (int bb = 0; bb < nb; ++bb) {
+            const float av = leaky(tofloat(a.y[(size_t)(bc + bb) * a.F + fp]) * sc + sh, a.slope);
+#pragma unroll
+            for (int q = 0; q < JT / 4; ++q) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[bb * JT + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * av;
+            }
+        }
+    }
+    const int fr = fref_of(fp, a.s2);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int jj = j0 + j;
+        if (jj < a.L) a.dwmu[(size_t)jj * a.F + fr] = acc[j];
+        else if (jj < L2) a.dwvar[(size_t)(jj - a.L) * a.F + fr] = acc[j];
+    }
+}
+
+// decoder_input forward (models.py:162): d0[b][f'] = bd[f] + sum_l z[b][l] Wd[f][l]
+template <typename T>
+__global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict__ z, const float* __restrict__ wd,
+                                                        const float* __restrict__ bd, T* __restrict__ d0, int B, int F, int L, int s2) {
+    constexpr int BT = 16;
+    extern __shared__ __attribute__((aligned(16))) float z_s[];  // [BT][L]
+    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, b0 = blockIdx.y * BT, fr = fref_of(fp, s2);
+    for (int i = tid; i < BT * L; i += 256) z_s[i] = (b0 + i / L < B) ? z[(size_t)b0 * L + i] : 0.f;
+    __syncthreads();
+    float acc[BT];
+    const float bias = bd[fr];
+#pragma unroll
+    for (int bb = 0; bb < BT; ++bb) acc[bb] = bias;
+    const float* wrow = wd + (size_t)fr * L;
+    for (int l = 0; l < L; l += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + l);
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[bb * L + l]);
+            acc[bb] += zz[0] * w[0] + zz[1] * w[1] + zz[2] * w[2] + zz[3] * w[3];
+        }
+    }
+#pragma unroll
+    for (int bb = 0; bb < BT; ++bb)
+        if (b0 + bb < B) d0[(size_t)(b0 + bb) * F + fp] = fromfloat<T>(acc[bb]);
+}
+
+// decoder_input weight/bias gradient: dWd[f][l] = sum_b dd0[b][f'] z[b][l]; dbd[f] = sum_b dd0[b][f']
+template <typename T>
+__global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ dd0, const float* __restrict__ z,
+                                                          float* __restrict__ dwd, float* __restrict__ dbd, int B, int F, int L, int s2) {
+    constexpr int LT = 32, BC = 64;
+    __shared__ __attribute__((aligned(16))) float z_s[BC * LT];
+    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, l0 = blockIdx.y * LT, fr = fref_of(fp, s2);
+    float acc[LT], sb = 0.f;
+#pragma unroll
+    for (int l = 0; l < LT; ++l) acc[l] = 0.f;
+    for (int bc = 0; bc < B; bc += BC) {
+        __syncthreads();
+        for (int i = tid; i < BC * LT; i += 256) {
+            const int bb = i / LT, l = i % LT;
+            z_s[i] = (bc + bb < B && l0 + l < L) ? z[(size_t)(bc + bb) * L + l0 + l] : 0.f;
+        }
+        __syncthreads();
+        const int nb = min(BC, B - bc);
+        for (int bb = 0; bb < nb; ++bb) {
+            const float g = tofloat(dd0[(size_t)(bc + bb) * F + fp]);
+            sb += g;
+#pragma unroll
+            for (int q = 0; q < LT / 4; ++q) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[bb * LT + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += zz[e] * g;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+        if (l0 + l < L) dwd[(size_t)fr * L + l0 + l] = acc[l];
+    if (blockIdx.y == 0) dbd[fr] = sb;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing: f32 reference layouts -> MFMA B-operand images [tap][K/8][N][8] of T
+struct PackDesc {
+    const float* src; const float* src2; void* dst;
+    int kind;     // 0 conv [A][Bc][9]; 1 fc (mu|var -> [F/8][npad][8]); 2 decoder_input; 3 tap-major f32 copy [9][C]
+    int A, Bc, k_is_first, npad, L, s2;
+    long n;       // elements of dst
+};
+template <typename T>
+__global__ void pack_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    T* dst = reinterpret_cast<T*>(d.dst);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long)gridDim.x * blockDim.x) {
+        if (d.kind == 0) {
+            const int K = d.k_is_first ? d.A : d.Bc, N = d.k_is_first ? d.Bc : d.A;
+            const int e = i & 7; long r = i >> 3; const int n = r % N; r /= N; const int kg = r % (K >> 3); const int t = r / (K >> 3);
+            const int k = kg * 8 + e;
+            const int ai = d.k_is_first ? k : n, bi = d.k_is_first ? n : k;
+            dst[i] = fromfloat<T>(d.src[((long)ai * d.Bc + bi) * 9 + t]);
+        } else if (d.kind == 1) {
+            const int e = i & 7; long r = i >> 3; const int n = r % d.npad; const long fp = (r / d.npad) * 8 + e;
+            const long F = (long)256 * d.s2; const long fr = (fp & 255) * d.s2 + (fp >> 8);
+            float v = 0.f;
+            if (n < d.L) v = d.src[(long)n * F + fr]; else if (n < 2 * d.L) v = d.src2[(long)(n - d.L) * F + fr];
+            dst[i] = fromfloat<T>(v);
+        } else if (d.kind == 2) {
+            const int e = i & 7; long r = i >> 3; const int n = r % d.npad; const long fp = (r / d.npad) * 8 + e;
+            const long fr = (fp & 255) * d.s2 + (fp >> 8);
+            dst[i] = fromfloat<T>(n < d.L ? d.src[fr * d.L + n] : 0.f);
+        } else {
+            const int t = i / d.A, c = i % d.A;   // dst f32 [9][C] from src [C][9]
+            reinterpret_cast<float*>(d.dst)[i] = d.src[c * 9 + t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// torch.optim.AdamW (train.py:228) over up to two contiguous parameter ranges
+// (encoder group, decoder group), each with its own OneCycle lr / beta1 (train.py:233-238).
+struct AdamGroup { long off, n; float lr, beta1; };
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    AdamGroup grp[2]; int ngrp;
+    float beta2, eps, weight_decay, grad_scale; int step;
+};
+__global__ void adamw_kernel(AdamArgs a) {
+    const AdamGroup gr = a.grp[blockIdx.y];
+    const double bc1 = 1.0 - pow((double)gr.beta1, (double)a.step), bc2 = 1.0 - pow((double)a.beta2, (double)a.step);
+    const float step_size = (float)((double)gr.lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const float decay = 1.f - gr.lr * a.weight_decay;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < gr.n; i += (long)gridDim.x * blockDim.x) {
+        const long k = gr.off + i;
+        const float g = a.g[k] * a.grad_scale;
+        float p = a.p[k] * decay;
+        const float m = a.m[k] * gr.beta1 + (1.f - gr.beta1) * g;
+        const float v = a.v[k] * a.beta2 + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+        p -= step_size * (m / denom);
+        a.p[k] = p; a.m[k] = m; a.v[k] = v;
+    }
+}

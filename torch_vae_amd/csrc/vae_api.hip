@@ -1,0 +1,739 @@
+// Context, launch sequencing and the C ABI (include/vae_step.h) of the VAE step.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/vae_step.h"
+
+static thread_local std::string g_err;
+static int vae_set_error(const char* what, const char* why) {
+    g_err = std::string(what) + ": " + why;
+    return -1;
+}
+
+#include "common.cuh"
+#include "conv_mfma.cuh"
+#include "edge_kernels.cuh"
+
+#define LAUNCH_CHECK(name)                                                        \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) return vae_set_error(name, hipGetErrorString(_e)); \
+    } while (0)
+
+static const int kBnC[8] = {32, 64, 128, 256, 128, 64, 32, 32};
+static const float kSlope = 0.01f;   // nn.LeakyReLU() default (models.py:47,70,79)
+static const float kBnEps = 1e-5f;   // nn.BatchNorm2d default eps
+static const float kBnMom = 0.1f;    // nn.BatchNorm2d default momentum
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// ---------------------------------------------------------------------------
+extern "C" const char* vae_last_error(void) { return g_err.c_str(); }
+extern "C" int vae_abi_version(void) { return 1; }
+
+static void param_shapes(int H, int L, int gen, int64_t* sizes) {
+    const int s = gen ? H / 16 : 2;
+    const int64_t F = 256LL * s * s;
+    const int enc_ci[4] = {1, 32, 64, 128}, enc_co[4] = {32, 64, 128, 256};
+    int k = 0;
+    for (int i = 0; i < 4; ++i) { sizes[k++] = 9LL * enc_ci[i] * enc_co[i]; sizes[k++] = enc_co[i]; sizes[k++] = enc_co[i]; sizes[k++] = enc_co[i]; }
+    sizes[k++] = L * F; sizes[k++] = L; sizes[k++] = L * F; sizes[k++] = L; sizes[k++] = F * L; sizes[k++] = F;
+    const int dec_ci[3] = {256, 128, 64}, dec_co[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i) { sizes[k++] = 9LL * dec_ci[i] * dec_co[i]; sizes[k++] = dec_co[i]; sizes[k++] = dec_co[i]; sizes[k++] = dec_co[i]; }
+    sizes[k++] = 9 * 32 * 32; sizes[k++] = 32; sizes[k++] = 32; sizes[k++] = 32; sizes[k++] = 9 * 32; sizes[k++] = 1;
+}
+
+extern "C" int vae_param_layout(int H, int L, int gen, int64_t* offsets, int64_t* sizes, int64_t* total) {
+    if (H < 32 || (H & (H - 1)) || (!gen && H != 32)) return vae_set_error("vae_param_layout", "img_size must be a power of two >= 32 (exactly 32 unless generalised)");
+    if (L < 4 || L % 4) return vae_set_error("vae_param_layout", "latent_dim must be a positive multiple of 4");
+    param_shapes(H, L, gen, sizes);
+    int64_t off = 0;
+    for (int i = 0; i < VAE_NUM_PARAMS; ++i) { offsets[i] = off; off += align_up(sizes[i], 64); }
+    *total = off;
+    return 0;
+}
+extern "C" int vae_bn_layout(int64_t* offsets, int64_t* channels, int64_t* total) {
+    int64_t off = 0;
+    for (int i = 0; i < 8; ++i) { offsets[i] = off; channels[i] = kBnC[i]; off += 2 * kBnC[i]; }
+    *total = off;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+struct Tiling { int lth, ltw, lTB, tiles_x, tiles_y; };
+static Tiling make_tiling(int Hs, int Ws, int pixels) {
+    const int tw = std::min(Ws, pixels >= 128 ? 16 : 8), th = std::min(Hs, pixels / tw), TB = pixels / (th * tw);
+    Tiling t; t.lth = ilog2(th); t.ltw = ilog2(tw); t.lTB = ilog2(TB); t.tiles_x = Ws / tw; t.tiles_y = Hs / th;
+    return t;
+}
+
+struct BnLayer {
+    int C, H, W;            // spatial size of the tensor this BN normalises
+    double* stat_f; double* stat_b; float* block; void* y; void* dz;
+    int p_gamma, p_beta, p_convw, p_convb;
+};
+
+struct vae_ctx {
+    int H, L, maxB, dtype, gen, s, s2; int64_t F; int npad_fc, npad_di; size_t esz;
+    int64_t poff[VAE_NUM_PARAMS], psz[VAE_NUM_PARAMS], ptotal, bnoff[8], bnc[8], bntotal;
+    BnLayer lay[8];
+    void *d0, *dd0;
+    float *eps, *dlat, *dlogit, *dlogit2, *ident, *wout_t;
+    void* wp_fwd[8]; void* wp_dg[8];   // indexed by BN layer id (1..7); [0] unused
+    void *fcpack, *dipack;
+    PackDesc* d_descs; std::vector<PackDesc> h_descs; const float* packed_for;
+    float* slab; size_t slab_floats;
+    double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
+    // last forward
+    int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
+    int use_tr16; int64_t ws_bytes;
+    std::vector<void*> allocs;
+};
+
+template <typename T> static T* dalloc(vae_ctx* c, size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) return nullptr;
+    c->allocs.push_back(p); c->ws_bytes += (int64_t)std::max<size_t>(n * sizeof(T), 256);
+    return reinterpret_cast<T*>(p);
+}
+
+extern "C" void vae_destroy(vae_ctx* c) {
+    if (!c) return;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
+
+static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out) {
+    int WA, WB;
+    if (CA >= 64 && CB >= 64) { WA = 2; WB = 2; } else if (CB == 32 && CA >= 64) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
+    const int WK = 4 / (WA * WB);
+    Tiling t = make_tiling(Hs, Ws, WG_KP);
+    const int TB = 1 << t.lTB;
+    const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
+    const size_t per = (size_t)9 * CA * CB;
+    int nsplit = std::max(1, 768 / chan_tiles);
+    const size_t cap = (size_t)(24u << 20) / 4;  // bound slab traffic to 24 MiB per layer
+    nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / (per * WK)));
+    nsplit = std::min(nsplit, n_tiles);
+    const int tps = (n_tiles + nsplit - 1) / nsplit;
+    nsplit = (n_tiles + tps - 1) / tps;
+    *nsplit_out = nsplit; *tps_out = tps; *WA_out = WA; *WB_out = WB;
+    return per * nsplit * WK;
+}
+
+extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
+    vae_ctx* c = new vae_ctx();
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1;
+    c->packed_for = nullptr; c->B = 0; c->trained = 0;
+    if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
+    if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
+    if (maxB < 1) { vae_set_error("vae_create", "max_batch < 1"); delete c; return nullptr; }
+    vae_bn_layout(c->bnoff, c->bnc, &c->bntotal);
+    c->s = gen ? H / 16 : 2; c->s2 = c->s * c->s; c->F = 256LL * c->s2;
+    c->npad_fc = (int)align_up(2 * L, 32); c->npad_di = (int)align_up(L, 32);
+    c->esz = dtype == VAE_DTYPE_BF16 ? 2 : 4;
+    const size_t B = maxB;
+    // BN'd tensors: encoder outputs H/2..H/16, decoder outputs 2s..8s, final convT output H.
+    const int hs[8] = {H / 2, H / 4, H / 8, H / 16, 2 * c->s, 4 * c->s, 8 * c->s, 16 * c->s};
+    size_t nd = 0;
+    for (int i = 0; i < 8; ++i) nd += 4 * kBnC[i];
+    c->n_dstats = nd + 8;
+    c->dstats = dalloc<double>(c, c->n_dstats);
+    bool ok = c->dstats != nullptr;
+    double* dp = c->dstats;
+    for (int i = 0; i < 8 && ok; ++i) {
+        BnLayer& l = c->lay[i];
+        l.C = kBnC[i]; l.H = hs[i]; l.W = hs[i];
+        l.stat_f = dp; dp += 2 * l.C;
+        const size_t n = B * l.H * l.W * l.C;
+        l.y = dalloc<char>(c, n * c->esz); l.dz = dalloc<char>(c, n * c->esz); l.block = dalloc<float>(c, LC_ROWS * l.C);
+        ok = l.y && l.dz && l.block;
+        const int base = i < 4 ? 4 * i : (i < 7 ? 22 + 4 * (i - 4) : 34);
+        l.p_convw = base; l.p_convb = base + 1; l.p_gamma = base + 2; l.p_beta = base + 3;
+    }
+    for (int i = 0; i < 8; ++i) { c->lay[i].stat_b = dp; dp += 2 * kBnC[i]; }
+    c->accum = dp;
+    if (ok) {
+        c->d0 = dalloc<char>(c, B * c->F * c->esz); c->dd0 = dalloc<char>(c, B * c->F * c->esz);
+        c->eps = dalloc<float>(c, B * L); c->dlat = dalloc<float>(c, B * 2 * L);
+        c->dlogit = dalloc<float>(c, B * H * H); c->dlogit2 = dalloc<float>(c, B * H * H); c->ident = dalloc<float>(c, 3 * 256); c->wout_t = dalloc<float>(c, 288);
+        ok = c->d0 && c->dd0 && c->eps && c->dlat && c->dlogit && c->dlogit2 && c->ident && c->wout_t;
+    }
+    // packed weight images
+    const int ci[8] = {1, 32, 64, 128, 256, 128, 64, 32}, co[8] = {32, 64, 128, 256, 128, 64, 32, 32};
+    for (int i = 1; i < 8 && ok; ++i) {
+        const size_t n = (size_t)9 * ci[i] * co[i];
+        c->wp_fwd[i] = dalloc<char>(c, n * c->esz); c->wp_dg[i] = dalloc<char>(c, n * c->esz);
+        ok = c->wp_fwd[i] && c->wp_dg[i];
+    }
+    if (ok) {
+        c->fcpack = dalloc<char>(c, (size_t)c->F * c->npad_fc * c->esz);
+        c->dipack = dalloc<char>(c, (size_t)c->F * c->npad_di * c->esz);
+        c->d_descs = dalloc<PackDesc>(c, 32);
+        ok = c->fcpack && c->dipack && c->d_descs;
+    }
+    // slab: max over all split-K users
+    size_t slab = 1024 * 288;  // conv1 wgrad / convout bwd: up to 1024 workgroups x 288
+    if (ok) {
+        int a, b2, wa, wb;
+        for (int i = 1; i < 4; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H, c->lay[i].W, co[i], ci[i], &a, &b2, &wa, &wb));
+        for (int i = 4; i < 8; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H / 2, c->lay[i].W / 2, ci[i], co[i], &a, &b2, &wa, &wb));
+        const size_t ksteps = c->F / 16;
+        slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_fc);
+        slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_di);
+        c->slab_floats = slab;
+        c->slab = dalloc<float>(c, slab);
+        ok = c->slab != nullptr;
+    }
+    if (!ok) { vae_set_error("vae_create", "hipMalloc failed"); vae_destroy(c); return nullptr; }
+    std::vector<float> id(3 * 256, 0.f);
+    for (int i = 0; i < 256; ++i) id[i] = 1.f;
+    if (hipMemcpy(c->ident, id.data(), id.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { vae_set_error("vae_create", "memcpy failed"); vae_destroy(c); return nullptr; }
+    return c;
+}
+
+extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
+    if (!c) return vae_set_error("vae_set_option", "null ctx");
+    if (!strcmp(name, "use_tr16")) { c->use_tr16 = value; return 0; }
+    return vae_set_error("vae_set_option", "unknown option");
+}
+
+// ---------------------------------------------------------------------------
+template <typename K> static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return vae_set_error("lds", "tile needs more than 160 KiB LDS");
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return vae_set_error("hipFuncSetAttribute", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <typename T>
+static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    Tiling t = make_tiling(a.Hs, a.Ws, 128);
+    a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
+    const int n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    const int NT = std::min(4, a.Cout / 32);
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (2 * th + 1) * (2 * tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
+    dim3 grid(n_tiles, a.Cout / (32 * NT));
+#define DOWN_CASE(N) { if (set_lds(down_kernel<T, N>, lds)) return -1; hipLaunchKernelGGL((down_kernel<T, N>), grid, dim3(256), lds, st, a); }
+    if (NT == 1) DOWN_CASE(1) else if (NT == 2) DOWN_CASE(2) else DOWN_CASE(4)
+#undef DOWN_CASE
+    LAUNCH_CHECK("down_kernel");
+    return 0;
+}
+
+template <typename T>
+static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    Tiling t = make_tiling(a.Hs, a.Ws, 128);
+    a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
+    const int n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    const int NT = std::min(2, a.Cout / 32);
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (th + 1) * (tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
+    dim3 grid(n_tiles, a.Cout / (32 * NT));
+#define UP_CASE(N) { if (set_lds(up_kernel<T, N>, lds)) return -1; hipLaunchKernelGGL((up_kernel<T, N>), grid, dim3(256), lds, st, a); }
+    if (NT == 1) UP_CASE(1) else UP_CASE(2)
+#undef UP_CASE
+    LAUNCH_CHECK("up_kernel");
+    return 0;
+}
+
+static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int CA, int CB, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB);
+    LAUNCH_CHECK("reduce_slab_kernel");
+    return 0;
+}
+
+template <typename T>
+static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st) {
+    int nsplit, tps, WA, WB;
+    const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB);
+    if (need > c->slab_floats) return vae_set_error("wgrad", "slab too small");
+    Tiling t = make_tiling(a.Hs, a.Ws, WG_KP);
+    a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
+    a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
+    a.slab = c->slab; a.use_tr16 = c->use_tr16;
+    const int WK = 4 / (WA * WB);
+    const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
+                       (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16);
+    dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
+#define WG_CASE(A_, B_) { if (set_lds(wgrad_kernel<T, A_, B_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_>), grid, dim3(256), lds, st, a); }
+    if (WA == 2 && WB == 2) WG_CASE(2, 2) else if (WA == 2 && WB == 1) WG_CASE(2, 1) else WG_CASE(1, 1)
+#undef WG_CASE
+    LAUNCH_CHECK("wgrad_kernel");
+    return launch_reduce(c->slab, nsplit * WK, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
+}
+
+template <typename T>
+static int launch_dense(vae_ctx* c, DenseArgs<T> a, int* nsplit_out, hipStream_t st) {
+    const int NT = std::min(4, a.Npad / 32);
+    const int mt = (a.M + 127) / 128, ntile = a.Npad / (32 * NT), ksteps = a.K / 16;
+    int nsplit = std::max(1, std::min(ksteps, 512 / std::max(1, mt * ntile)));
+    a.ksteps_per_split = (ksteps + nsplit - 1) / nsplit;
+    nsplit = (ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;
+    if ((size_t)nsplit * a.M * a.Npad > c->slab_floats) return vae_set_error("dense", "slab too small");
+    a.slab = c->slab;
+    dim3 grid(mt, nsplit, ntile);
+    if (NT == 1) hipLaunchKernelGGL((dense_kernel<T, 1>), grid, dim3(256), 0, st, a);
+    else if (NT == 2) hipLaunchKernelGGL((dense_kernel<T, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dense_kernel<T, 4>), grid, dim3(256), 0, st, a);
+    LAUNCH_CHECK("dense_kernel");
+    *nsplit_out = nsplit;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double counter_uniform(unsigned long long i, unsigned long long seed, unsigned long long stream) {
+    unsigned long long base = splitmix64(seed);
+    base = splitmix64(base ^ (stream * 0xD1342543DE82EF95ULL));
+    const unsigned long long bits = splitmix64(base + i * 0x2545F4914F6CDD1DULL);
+    return (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+// eps ~ N(0,1): Box-Muller on the counter generator (same as oracle.counter_normal(n, seed, 5))
+__global__ void counter_normal_kernel(float* out, long n, unsigned long long seed, unsigned long long stream) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u1 = counter_uniform(i, seed, 2 * stream + 1000003ULL), u2 = counter_uniform(i, seed, 2 * stream + 1000004ULL);
+    out[i] = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * 3.14159265358979323846 * u2));
+}
+// data_generators.py:45-77 restated with the counter generator (stream 777); one workgroup per image
+__global__ void synth_pianoroll_kernel(float* x, int H, unsigned long long seed, int max_lines) {
+    const int b = blockIdx.x;
+    const int width = 1 + (int)(counter_uniform(0, seed, 777) * 4);
+    const unsigned long long base = 1 + (unsigned long long)b * (1 + 4 * max_lines);
+    const int n_lines = 1 + (int)(counter_uniform(base, seed, 777) * max_lines);
+    for (int p = threadIdx.x; p < H * H; p += blockDim.x) {
+        const int py = p / H, px = p % H;
+        float v = 0.f;
+        for (int li = 0; li < n_lines; ++li) {
+            const unsigned long long k = base + 1 + 4ULL * li;
+            const bool vert = counter_uniform(k, seed, 777) < 0.5;
+            const int pos = (int)(counter_uniform(k + 1, seed, 777) * H);
+            const int start = (int)(counter_uniform(k + 2, seed, 777) * H);
+            const int end = start + (int)(counter_uniform(k + 3, seed, 777) * (H - start));
+            const int lo = max(0, pos - width / 2), hi = min(H, pos + width / 2 + 1);
+            const int along = vert ? py : px, across = vert ? px : py;
+            if (along >= start && along < end && across >= lo && across < hi) v = 1.f;
+        }
+        x[(size_t)b * H * H + p] = v;
+    }
+}
+extern "C" int vae_synth_pianoroll(float* x, int B, int H, uint64_t seed, vae_stream_t stream) {
+    hipLaunchKernelGGL(synth_pianoroll_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, H, (unsigned long long)seed, 20);
+    LAUNCH_CHECK("synth_pianoroll_kernel");
+    return 0;
+}
+
+__global__ void d2f_kernel(const double* s, float* o, int n, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (float)(s[i] * scale);
+}
+__global__ void zero_f32_kernel(float* o, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+static int pack_weights(vae_ctx* c, const float* params, hipStream_t st) {
+    std::vector<PackDesc>& d = c->h_descs;
+    if (c->packed_for != params || d.empty()) {
+        d.clear();
+        const int ci[8] = {1, 32, 64, 128, 256, 128, 64, 32}, co[8] = {32, 64, 128, 256, 128, 64, 32, 32};
+        for (int i = 1; i < 8; ++i) {
+            const bool conv = i < 4;  // Conv2d [co][ci][9] vs ConvTranspose2d [ci][co][9]
+            PackDesc p; memset(&p, 0, sizeof(p));
+            p.src = params + c->poff[c->lay[i].p_convw]; p.kind = 0; p.n = 9L * ci[i] * co[i];
+            p.A = conv ? co[i] : ci[i]; p.Bc = conv ? ci[i] : co[i];
+            p.dst = c->wp_fwd[i]; p.k_is_first = conv ? 0 : 1; d.push_back(p);   // K = ci
+            p.dst = c->wp_dg[i]; p.k_is_first = conv ? 1 : 0; d.push_back(p);    // K = co
+        }
+        PackDesc p; memset(&p, 0, sizeof(p));
+        p.kind = 1; p.src = params + c->poff[16]; p.src2 = params + c->poff[18]; p.dst = c->fcpack; p.npad = c->npad_fc; p.L = c->L; p.s2 = c->s2; p.n = c->F * c->npad_fc; d.push_back(p);
+        p.kind = 2; p.src = params + c->poff[20]; p.src2 = nullptr; p.dst = c->dipack; p.npad = c->npad_di; p.n = c->F * c->npad_di; d.push_back(p);
+        p.kind = 3; p.src = params + c->poff[38]; p.dst = c->wout_t; p.A = 32; p.n = 288; d.push_back(p);
+        HIP_CHECK_RET(hipMemcpyAsync(c->d_descs, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+        c->packed_for = params;
+    }
+    hipLaunchKernelGGL((pack_kernel<T>), dim3(64, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
+    LAUNCH_CHECK("pack_kernel");
+    return 0;
+}
+
+static int bn_finalize_fwd(vae_ctx* c, int i, const float* params, float* bn_running, int64_t* nbt, int train, hipStream_t st) {
+    const BnLayer& l = c->lay[i];
+    if (train) {
+        BnFwdArgs a;
+        a.stat = l.stat_f; a.gamma = params + c->poff[l.p_gamma]; a.beta = params + c->poff[l.p_beta]; a.block = l.block;
+        a.running_mean = bn_running ? bn_running + c->bnoff[i] : nullptr; a.running_var = bn_running ? bn_running + c->bnoff[i] + l.C : nullptr;
+        a.nbt = nbt ? reinterpret_cast<long long*>(nbt) + i : nullptr;
+        a.C = l.C; a.count = (double)c->B * l.H * l.W; a.eps = kBnEps; a.momentum = kBnMom; a.update_running = bn_running != nullptr;
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    } else {
+        if (!bn_running) return vae_set_error("vae_forward", "eval mode needs running statistics");
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(1), dim3(256), 0, st, params + c->poff[l.p_gamma], params + c->poff[l.p_beta],
+                           bn_running + c->bnoff[i], bn_running + c->bnoff[i] + l.C, l.block, l.C, kBnEps);
+    }
+    LAUNCH_CHECK("bn_finalize");
+    return 0;
+}
+
+template <typename T>
+static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
+                        const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, hipStream_t st) {
+    const int H = c->H, L = c->L;
+    c->B = B; c->trained = train; c->x = x; c->xhat = xhat; c->mu = mu; c->lv = lv; c->z = z;
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
+    if (pack_weights<T>(c, params, st)) return -1;
+    // encoder block 0
+    {
+        const long P = (long)B * (H / 2) * (H / 2);
+        const int grid = (int)std::min<long>((P + 63) / 64, 2048);
+        hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
+                           reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
+        LAUNCH_CHECK("conv1_fwd_kernel");
+        if (bn_finalize_fwd(c, 0, params, bn_running, nbt, train, st)) return -1;
+    }
+    for (int i = 1; i < 4; ++i) {
+        ConvArgs<T> a; memset(&a, 0, sizeof(a));
+        a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope;
+        a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
+        a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
+        a.B = B; a.Hs = c->lay[i].H; a.Ws = c->lay[i].W; a.Cin = c->lay[i - 1].C; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
+        if (launch_down<T>(c, a, st)) return -1;
+        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
+    }
+    // fc_mu | fc_var, reparameterize
+    {
+        DenseArgs<T> a; memset(&a, 0, sizeof(a));
+        a.A = reinterpret_cast<const T*>(c->lay[3].y); a.coef = c->lay[3].block; a.slope = kSlope; a.C = 256;
+        a.Bp = reinterpret_cast<const T*>(c->fcpack); a.M = B; a.K = (int)c->F; a.Npad = c->npad_fc;
+        int nsplit;
+        if (launch_dense<T>(c, a, &nsplit, st)) return -1;
+        if (eps) HIP_CHECK_RET(hipMemcpyAsync(c->eps, eps, (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
+        else {
+            hipLaunchKernelGGL(counter_normal_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, c->eps, (long)B * L, (unsigned long long)seed, 5ULL);
+            LAUNCH_CHECK("counter_normal_kernel");
+        }
+        LatentFwdArgs la;
+        la.slab = c->slab; la.nslab = nsplit; la.npad = c->npad_fc; la.bmu = params + c->poff[17]; la.bvar = params + c->poff[19];
+        la.eps = c->eps; la.mu = mu; la.lv = lv; la.z = z; la.accum = c->accum; la.B = B; la.L = L;
+        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, la);
+        LAUNCH_CHECK("latent_fwd_kernel");
+    }
+    // decoder_input
+    {
+        dim3 grid((unsigned)(c->F / 256), (B + 15) / 16);
+        hipLaunchKernelGGL((decin_fwd_kernel<T>), grid, dim3(256), 16 * L * 4, st, z, params + c->poff[20], params + c->poff[21],
+                           reinterpret_cast<T*>(c->d0), B, (int)c->F, L, c->s2);
+        LAUNCH_CHECK("decin_fwd_kernel");
+    }
+    for (int i = 4; i < 8; ++i) {
+        ConvArgs<T> a; memset(&a, 0, sizeof(a));
+        if (i == 4) { a.src0 = reinterpret_cast<const T*>(c->d0); a.coef = c->ident; a.slope = 1.f; a.Cin = 256; }
+        else { a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope; a.Cin = c->lay[i - 1].C; }
+        a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
+        a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
+        a.B = B; a.Hs = c->lay[i].H / 2; a.Ws = c->lay[i].W / 2; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
+        if (launch_up<T>(c, a, st)) return -1;
+        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
+    }
+    // output conv + sigmoid + reconstruction loss/gradient
+    {
+        ConvOutArgs a;
+        a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
+        a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
+        a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
+        hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
+        LAUNCH_CHECK("convout_fwd_kernel");
+    }
+    return 0;
+}
+
+static int bn_finalize_bwd(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
+    const BnLayer& l = c->lay[i];
+    BnBwdArgs a;
+    a.stat = l.stat_b; a.gamma = params + c->poff[l.p_gamma]; a.block = l.block;
+    a.dgamma = grads + c->poff[l.p_gamma]; a.dbeta = grads + c->poff[l.p_beta]; a.dconv_bias = grads + c->poff[l.p_convb];
+    a.C = l.C; a.count = (double)c->B * l.H * l.W;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    return 0;
+}
+
+template <typename T>
+static int backward_impl(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                         const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                         hipStream_t st) {
+    if (!c->B || !c->trained) return vae_set_error("vae_backward", "no train-mode forward to differentiate");
+    const int B = c->B, H = c->H, L = c->L;
+    size_t nfwd = 0;
+    for (int i = 0; i < 8; ++i) nfwd += 2 * kBnC[i];
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats + nfwd, 0, nfwd * sizeof(double), st));   // stat_b
+    HIP_CHECK_RET(hipMemsetAsync(c->accum + 2, 0, sizeof(double), st));
+    const float* dl_src = c->dlogit; const float* dl_scale = gscale;
+    if (g_xhat || !add_kl) {
+        // explicit upstream gradient on xhat (plus, when add_kl, the fused standard-ELBO term)
+        const long n = (long)B * H * H;
+        hipLaunchKernelGGL(dlogit_combine_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                           g_xhat, c->xhat, add_kl ? c->dlogit : nullptr, gscale, c->dlogit2, n);
+        LAUNCH_CHECK("dlogit_combine_kernel");
+        dl_src = c->dlogit2; dl_scale = nullptr;
+    }
+    // output conv backward + final_layer BN/LeakyReLU prologue
+    {
+        ConvOutBwdArgs a;
+        a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
+        a.dz = c->lay[7].dz; a.slab = c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
+        const long P = (long)B * H * H;
+        const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
+        LAUNCH_CHECK("convout_bwd_kernel");
+        if (launch_reduce(c->slab, grid, 288, grads + c->poff[38], 1, 32, st)) return -1;
+        hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st, c->accum + 2, grads + c->poff[39], 1, 1.f);
+        LAUNCH_CHECK("d2f_kernel");
+    }
+    // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
+    for (int i = 7; i >= 4; --i) {
+        if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
+        const BnLayer& l = c->lay[i];
+        const int Cin = i == 4 ? 256 : c->lay[i - 1].C;
+        WgradArgs<T> w; memset(&w, 0, sizeof(w));
+        if (i == 4) { w.s0 = reinterpret_cast<const T*>(c->d0); w.scoef = c->ident; w.sslope = 1.f; }
+        else { w.s0 = reinterpret_cast<const T*>(c->lay[i - 1].y); w.scoef = c->lay[i - 1].block; w.sslope = kSlope; }
+        w.s_two = 0;
+        w.g0 = reinterpret_cast<const T*>(l.dz); w.g1 = reinterpret_cast<const T*>(l.y); w.gcoef = l.block + LC_P0 * l.C; w.gslope = 1.f; w.g_two = 1;
+        w.B = B; w.Hs = l.H / 2; w.Ws = l.W / 2; w.CA = Cin; w.CB = l.C;
+        if (launch_wgrad<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        ConvArgs<T> a; memset(&a, 0, sizeof(a));
+        a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
+        a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
+        a.B = B; a.Hs = l.H / 2; a.Ws = l.W / 2; a.Cin = l.C; a.Cout = Cin;
+        if (i == 4) { a.out = reinterpret_cast<T*>(c->dd0); a.epi = EPI_PLAIN; }
+        else {
+            a.out = reinterpret_cast<T*>(c->lay[i - 1].dz); a.yout = reinterpret_cast<const T*>(c->lay[i - 1].y);
+            a.ocoef = c->lay[i - 1].block; a.oslope = kSlope; a.stat = c->lay[i - 1].stat_b; a.epi = EPI_BWD;
+        }
+        if (launch_down<T>(c, a, st)) return -1;
+    }
+    // decoder_input backward, reparameterisation + KL backward
+    {
+        dim3 grid((unsigned)(c->F / 256), (L + 31) / 32);
+        hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(c->dd0), c->z,
+                           grads + c->poff[20], grads + c->poff[21], B, (int)c->F, L, c->s2);
+        LAUNCH_CHECK("decin_wgrad_kernel");
+        DenseArgs<T> a; memset(&a, 0, sizeof(a));
+        a.A = reinterpret_cast<const T*>(c->dd0); a.coef = nullptr; a.slope = 1.f; a.C = 256;
+        a.Bp = reinterpret_cast<const T*>(c->dipack); a.M = B; a.K = (int)c->F; a.Npad = c->npad_di;
+        int nsplit;
+        if (launch_dense<T>(c, a, &nsplit, st)) return -1;
+        LatentBwdArgs lb;
+        lb.slab = c->slab; lb.nslab = nsplit; lb.npad = c->npad_di; lb.mu = c->mu; lb.lv = c->lv; lb.eps = c->eps; lb.gscale = gscale;
+        lb.gmu = g_mu; lb.glv = g_lv; lb.gz = g_z; lb.dlat = c->dlat; lb.B = B; lb.L = L; lb.kld_weight = kld_weight; lb.add_kl = add_kl;
+        hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, lb);
+        LAUNCH_CHECK("latent_bwd_kernel");
+        hipLaunchKernelGGL(colsum_kernel, dim3((2 * L + 63) / 64), dim3(64), 0, st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L);
+        LAUNCH_CHECK("colsum_kernel");
+    }
+    // fc_mu / fc_var backward
+    {
+        FcWgradArgs<T> w;
+        w.dlat = c->dlat; w.y = reinterpret_cast<const T*>(c->lay[3].y); w.coef = c->lay[3].block; w.slope = kSlope;
+        w.dwmu = grads + c->poff[16]; w.dwvar = grads + c->poff[18]; w.B = B; w.F = (int)c->F; w.L = L; w.s2 = c->s2;
+        hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32), dim3(256), 0, st, w);
+        LAUNCH_CHECK("fc_wgrad_kernel");
+        FcDgradArgs<T> d;
+        d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
+        d.ocoef = c->lay[3].block; d.slope = kSlope; d.gpre = g_pre; d.dz = reinterpret_cast<T*>(c->lay[3].dz); d.stat = c->lay[3].stat_b;
+        d.B = B; d.F = (int)c->F; d.L2 = 2 * L; d.s2 = c->s2;
+        hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + 15) / 16), dim3(256), 2 * L * 16 * 4, st, d);
+        LAUNCH_CHECK("fc_dgrad_kernel");
+    }
+    // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
+    for (int i = 3; i >= 1; --i) {
+        if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
+        const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
+        WgradArgs<T> w; memset(&w, 0, sizeof(w));
+        w.s0 = reinterpret_cast<const T*>(l.dz); w.s1 = reinterpret_cast<const T*>(l.y); w.scoef = l.block + LC_P0 * l.C; w.sslope = 1.f; w.s_two = 1;
+        w.g0 = reinterpret_cast<const T*>(lp.y); w.gcoef = lp.block; w.gslope = kSlope; w.g_two = 0;
+        w.B = B; w.Hs = l.H; w.Ws = l.W; w.CA = l.C; w.CB = lp.C;
+        if (launch_wgrad<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        ConvArgs<T> a; memset(&a, 0, sizeof(a));
+        a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
+        a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
+        a.out = reinterpret_cast<T*>(lp.dz); a.yout = reinterpret_cast<const T*>(lp.y); a.ocoef = lp.block; a.oslope = kSlope; a.stat = lp.stat_b; a.epi = EPI_BWD;
+        a.B = B; a.Hs = l.H; a.Ws = l.W; a.Cin = l.C; a.Cout = lp.C;
+        if (launch_up<T>(c, a, st)) return -1;
+    }
+    {
+        if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
+        const long P = (long)B * (H / 2) * (H / 2);
+        const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const T*>(c->lay[0].dz),
+                           reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, c->slab, B, H, H);
+        LAUNCH_CHECK("conv1_wgrad_kernel");
+        if (launch_reduce(c->slab, grid, 288, grads + c->poff[0], 32, 1, st)) return -1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int vae_forward(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
+                           const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, vae_stream_t stream) {
+    if (!c) return vae_set_error("vae_forward", "null ctx");
+    if (B < 1 || B > c->maxB) return vae_set_error("vae_forward", "batch exceeds the context's max_batch");
+    if (!x || !params || !xhat || !mu || !lv || !z) return vae_set_error("vae_forward", "null tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return c->dtype == VAE_DTYPE_BF16 ? forward_impl<bf16>(c, x, B, params, bn_running, nbt, eps, seed, train, xhat, mu, lv, z, st)
+                                      : forward_impl<float>(c, x, B, params, bn_running, nbt, eps, seed, train, xhat, mu, lv, z, st);
+}
+
+extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
+    if (!c || !c->B) return vae_set_error("vae_loss", "no forward");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->accum, out3,
+                       1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight);
+    LAUNCH_CHECK("loss_finalize_kernel");
+    return 0;
+}
+
+static double* g_generic_accum = nullptr;
+extern "C" int vae_elbo_generic(const float* xhat, const float* target, const float* mu, const float* lv, int64_t n, int B, int L,
+                                float kld_weight, float* out3, float* g_xhat, float* g_mu, float* g_lv, vae_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_generic_accum) HIP_CHECK_RET(hipMalloc(&g_generic_accum, 4 * sizeof(double)));
+    HIP_CHECK_RET(hipMemsetAsync(g_generic_accum, 0, 4 * sizeof(double), st));
+    hipLaunchKernelGGL(bce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st, xhat, target, g_xhat, g_generic_accum, (long)n, (float)(1.0 / (double)n));
+    LAUNCH_CHECK("bce_kernel");
+    hipLaunchKernelGGL(kld_only_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, mu, lv, g_generic_accum, B * L, kld_weight / (float)B, g_mu, g_lv);
+    LAUNCH_CHECK("kld_only_kernel");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, g_generic_accum, out3, 1.0 / (double)n, 1.0 / (double)B, kld_weight);
+    LAUNCH_CHECK("loss_finalize_kernel");
+    return 0;
+}
+
+extern "C" int vae_backward(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                            const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                            vae_stream_t stream) {
+    if (!c) return vae_set_error("vae_backward", "null ctx");
+    if (!x || !params || !grads) return vae_set_error("vae_backward", "null tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return c->dtype == VAE_DTYPE_BF16 ? backward_impl<bf16>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st)
+                                      : backward_impl<float>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st);
+}
+
+extern "C" int vae_adamw_step(float* params, const float* grads, float* m, float* v, int ngroups, const int64_t* offsets,
+                              const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float eps, float weight_decay,
+                              float grad_scale, int step, vae_stream_t stream) {
+    if (ngroups < 1 || ngroups > 2) return vae_set_error("vae_adamw_step", "1 or 2 groups");
+    if (step < 1) return vae_set_error("vae_adamw_step", "step is 1-based");
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = m; a.v = v; a.ngrp = ngroups; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.grad_scale = grad_scale; a.step = step;
+    long nmax = 0;
+    for (int i = 0; i < ngroups; ++i) { a.grp[i].off = offsets[i]; a.grp[i].n = sizes[i]; a.grp[i].lr = lrs[i]; a.grp[i].beta1 = beta1s[i]; nmax = std::max<long>(nmax, sizes[i]); }
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((nmax + 255) / 256, 2048), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK("adamw_kernel");
+    return 0;
+}
+
+extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, float* grads, float* m, float* v, float* bn_running,
+                              int64_t* nbt, const float* eps, uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
+                              const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
+                              float weight_decay, int step, float* xhat, float* mu, float* lv, float* z, float* out3, vae_stream_t stream) {
+    if (vae_forward(c, x, B, params, bn_running, nbt, eps, seed, 1, xhat, mu, lv, z, stream)) return -1;
+    if (vae_loss(c, kld_weight, out3, stream)) return -1;
+    if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
+    if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, 1.f, step, stream)) return -1;
+    return 0;
+}
+
+extern "C" int vae_pre_latents(vae_ctx* c, float* out, vae_stream_t stream) {
+    if (!c || !c->B) return vae_set_error("vae_pre_latents", "no forward");
+    const long n = (long)c->B * c->F;
+    if (c->dtype == VAE_DTYPE_BF16)
+        hipLaunchKernelGGL((pre_latents_kernel<bf16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const bf16*>(c->lay[3].y), c->lay[3].block, kSlope, out, c->B, (int)c->F, c->s2);
+    else
+        hipLaunchKernelGGL((pre_latents_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(c->lay[3].y), c->lay[3].block, kSlope, out, c->B, (int)c->F, c->s2);
+    LAUNCH_CHECK("pre_latents_kernel");
+    return 0;
+}
+extern "C" int vae_last_eps(vae_ctx* c, float* out, vae_stream_t stream) {
+    if (!c || !c->B) return vae_set_error("vae_last_eps", "no forward");
+    HIP_CHECK_RET(hipMemcpyAsync(out, c->eps, (size_t)c->B * c->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* in, float* out, long n, int C, int HW) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = i % C; const long pix = (i / C) % HW; const long b = i / ((long)C * HW);
+    out[(b * C + ch) * HW + pix] = tofloat(in[i]);
+}
+extern "C" int vae_debug_tensor(vae_ctx* c, int which, float* out, int64_t capacity, vae_stream_t stream) {
+    if (!c || !c->B) return vae_set_error("vae_debug_tensor", "no forward");
+    const void* src; int C, HW;
+    if (which >= 0 && which < 16) { const BnLayer& l = c->lay[which & 7]; src = which < 8 ? l.y : l.dz; C = l.C; HW = l.H * l.W; }
+    else if (which == 16 || which == 17) { src = which == 16 ? c->d0 : c->dd0; C = 256; HW = c->s2; }
+    else return vae_set_error("vae_debug_tensor", "bad tensor id");
+    const long n = (long)c->B * C * HW;
+    if (n > capacity) return vae_set_error("vae_debug_tensor", "output too small");
+    if (c->dtype == VAE_DTYPE_BF16)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16*>(src), out, n, C, HW);
+    else
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(src), out, n, C, HW);
+    LAUNCH_CHECK("nhwc_to_nchw_kernel");
+    return 0;
+}
+
+// Self-test of ds_read_b64_tr_b16: a 16x32 tile of 16-bit words M[k][c] = k*32 + c staged as
+// [k][c]; the k-major fragment of lane (r,h) must come back as M[8h+j][r].
+__global__ void selftest_tr16_kernel(int* bad) {
+    __shared__ __attribute__((aligned(16))) short tile[16 * 32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 16 * 32; i += 64) tile[i] = (short)i;
+    __syncthreads();
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, r = lane & 31, h = lane >> 5;
+    int nbad = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int k = 8 * (g4 >> 1) + 4 * half + q;
+        const char* ad = reinterpret_cast<const char*>(tile) + k * 64 + (16 * (g4 & 1) + 4 * p) * 2;
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((int)v[e] != (8 * h + 4 * half + e) * 32 + r) ++nbad;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+extern "C" int vae_selftest_tr16(vae_stream_t stream) {
+    int* d = nullptr; int h = 0;
+    HIP_CHECK_RET(hipMalloc(&d, 4));
+    HIP_CHECK_RET(hipMemsetAsync(d, 0, 4, (hipStream_t)stream));
+    hipLaunchKernelGGL(selftest_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
+    HIP_CHECK_RET(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+    (void)hipFree(d);
+    if (h) { char buf[64]; snprintf(buf, sizeof(buf), "%d mismatching elements", h); return vae_set_error("ds_read_b64_tr_b16 self-test", buf); }
+    return 0;
+}

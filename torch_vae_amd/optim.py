@@ -1,0 +1,90 @@
+"""Fused AdamW over the model's flat parameter buffer.
+
+Behaves as ``torch.optim.AdamW`` (train.py:228): same ``param_groups`` keys, so
+``torch.optim.lr_scheduler.OneCycleLR`` (train.py:233-238) drives ``lr`` and
+``betas[0]`` exactly as it does for the reference.  ``step()`` is one kernel launch
+for all groups (include/vae_step.h: vae_adamw_step).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._model = None
+        self._m = self._v = None
+        self._step = 0
+        self.grad_scale = 1.0
+        if len(self.param_groups) > 2:
+            raise ValueError("FusedAdamW supports at most two parameter groups (encoder, decoder)")
+
+    def _bind(self):
+        if self._model is not None:
+            return
+        owners = {getattr(p, "_vae_owner", None) for g in self.param_groups for p in g["params"]}
+        if len(owners) != 1 or None in owners:
+            raise ValueError("FusedAdamW needs parameters of one torch_vae_amd VanillaVAE that is already on the GPU "
+                             "(move the model with .to('cuda') before building the optimiser)")
+        self._model = next(iter(owners))()
+        model = self._model
+        self._ranges = []
+        for g in self.param_groups:
+            idx = sorted(p._vae_index for p in g["params"])
+            if idx != list(range(idx[0], idx[-1] + 1)):
+                raise ValueError("each FusedAdamW group must be a contiguous run of model parameters")
+            start = model._offs[idx[0]]
+            self._ranges.append((start, model._offs[idx[-1]] + model._sizes[idx[-1]] - start))
+        flat = model.flat_parameters()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        for g in self.param_groups:
+            for p in g["params"]:
+                o, n = model._offs[p._vae_index], model._sizes[p._vae_index]
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[o:o + n].view(p.shape),
+                                 "exp_avg_sq": self._v[o:o + n].view(p.shape)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._bind()
+        model = self._model
+        gflat = model.flat_grads()
+        active = []
+        for g, rng in zip(self.param_groups, self._ranges):
+            grads = [p.grad for p in g["params"]]
+            if all(gr is None for gr in grads):
+                continue  # torch skips parameters without gradients
+            for p, gr in zip(g["params"], grads):
+                o, n = model._offs[p._vae_index], model._sizes[p._vae_index]
+                if gr is None:
+                    raise NotImplementedError("a FusedAdamW group with only some gradients set")
+                if gr.data_ptr() != gflat.data_ptr() + 4 * o:
+                    gflat[o:o + n].view(p.shape).copy_(gr)  # foreign gradient tensor: stage it
+            active.append((g, rng))
+        if not active:
+            return loss
+        self._step += 1
+        n = len(active)
+        offs = (C.c_int64 * n)(*[r[0] for _, r in active])
+        sizes = (C.c_int64 * n)(*[r[1] for _, r in active])
+        lrs = (C.c_float * n)(*[float(g["lr"]) for g, _ in active])
+        b1s = (C.c_float * n)(*[float(g["betas"][0]) for g, _ in active])
+        g0 = active[0][0]
+        for g, _ in active:
+            if (g["betas"][1], g["eps"], g["weight_decay"]) != (g0["betas"][1], g0["eps"], g0["weight_decay"]):
+                raise NotImplementedError("groups must share beta2, eps and weight_decay")
+        _lib.check(_lib.lib().vae_adamw_step(
+            model.flat_parameters().data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n, offs, sizes,
+            lrs, b1s, float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(self.grad_scale),
+            self._step, torch.cuda.current_stream().cuda_stream), "vae_adamw_step")
+        for g, _ in active:
+            for p in g["params"]:
+                self.state[p]["step"] += 1
+        return loss

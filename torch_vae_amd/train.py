@@ -1,0 +1,167 @@
+"""MI355X-native mirror of the reference's step loop ``train.train_one_epoch`` (train.py:554-767)
+plus the optimiser/scheduler construction it depends on (train.py:201-238).
+
+Same signature, same order of operations (forward -> zero_grad -> loss -> backward ->
+optimizer.step -> scheduler.step), same counters, console line and return tuple.  When the
+model is this package's VanillaVAE, the criterion is ``model.loss`` and the optimiser is
+``FusedAdamW``, each step is the fused HIP chain (no autograd graph); any other combination
+still runs through the same kernels via autograd.  With ``torch.distributed`` initialised
+(one process per GPU, RCCL) the optimised gradient ranges are all-reduced before the update
+-- plain data parallelism, which the reference only prepares for (train.py:165-166,201,663).
+"""
+from __future__ import annotations
+
+import time
+from contextlib import nullcontext
+
+import torch
+import torch.distributed as dist
+
+from .models import VanillaVAE
+from .optim import FusedAdamW
+
+BASE_BATCH_SIZE = 128  # train.py: lr_relative is quoted per 128 samples
+
+
+def build_optimizer(config, model, steps_per_epoch: int):
+    """train.py:201-238: lr = lr_relative * batch_size / 128; AdamW over the encoder and decoder
+    groups only (fc_mu, fc_var, decoder_input, final_layer are never updated); OneCycleLR."""
+    world = int(getattr(config, "world_size", 1))
+    config.batch_size = config.batch_size_per_gpu * world
+    config.lr = config.lr_relative * config.batch_size / BASE_BATCH_SIZE
+    params = []
+    if not getattr(config, "freeze_encoder", False):
+        params.append({"params": model.encoder.parameters(), "lr": config.lr * getattr(config, "lr_encoder_mult", 1.0),
+                       "name": "encoder"})
+    params.append({"params": model.decoder.parameters(), "lr": config.lr * getattr(config, "lr_decoder_mult", 1.0),
+                   "name": "decoder"})
+    name = getattr(config, "optimizer", "AdamW")
+    if name == "AdamW" and isinstance(model, VanillaVAE):
+        optimizer = FusedAdamW(params, lr=config.lr, weight_decay=getattr(config, "weight_decay", 0.0))
+    else:
+        optimizer = getattr(torch.optim, name)(params, lr=config.lr, weight_decay=getattr(config, "weight_decay", 0.0))
+    if getattr(config, "scheduler", "OneCycle").lower() != "onecycle":
+        raise NotImplementedError(f"Scheduler {config.scheduler} not supported.")
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(
+        optimizer, [p["lr"] for p in optimizer.param_groups], epochs=config.epochs, steps_per_epoch=steps_per_epoch)
+    return optimizer, scheduler
+
+
+def _dp_world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_gradients(model: VanillaVAE, optimizer=None):
+    """Sum the optimised gradient ranges over ranks (RCCL all-reduce over xGMI); the mean is applied
+    inside the AdamW kernel (grad_scale = 1/world).  Returns the async work handles."""
+    world = _dp_world()
+    if world == 1:
+        return []
+    g = model.flat_grads()
+    works = []
+    for prefix in ("decoder", "encoder"):  # decoder gradients are produced first by the backward chain
+        off, n = model.group_range(prefix)
+        works.append(dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+    if optimizer is not None and hasattr(optimizer, "grad_scale"):
+        optimizer.grad_scale = 1.0 / world
+    return works
+
+
+def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, device="cuda", epoch=1, n_epoch=None,
+                    total_step=0, n_samples_seen=0, verbose=False):
+    """Train the model for one epoch (train.py:554-767)."""
+    model.train()
+    log_wandb = bool(getattr(config, "log_wandb", False))
+    if log_wandb:
+        import wandb  # lazy, optional (train.py:608-610)
+    loss_epoch = 0
+    if getattr(config, "print_interval", None) is None:
+        config.print_interval = config.log_interval
+    world = _dp_world()
+    fused = (isinstance(model, VanillaVAE) and isinstance(optimizer, FusedAdamW)
+             and getattr(criterion, "__self__", None) is model and not getattr(config, "freeze_encoder", False))
+    for batch_idx, (stimuli, y_true) in enumerate(dataloader):
+        batch_size_this_gpu = stimuli.shape[0]
+        stimuli = stimuli.to(device)
+        y_true = y_true.to(device)
+        if fused:
+            # train.py:634-656 as one HIP chain: forward, ELBO, backward, [all-reduce], AdamW
+            out3, reconstruction = model.fused_forward_backward(stimuli, use_device_eps=False)
+            for w in allreduce_gradients(model, optimizer):
+                w.wait()
+            optimizer.step()
+        else:
+            with torch.no_grad() if getattr(config, "freeze_encoder", False) else nullcontext():
+                output = model.forward(stimuli)
+                reconstruction = output["output"]
+            optimizer.zero_grad()
+            loss_output = criterion(output)
+            loss_output["loss"].backward()
+            if isinstance(model, VanillaVAE):
+                for w in allreduce_gradients(model, optimizer):
+                    w.wait()
+            optimizer.step()
+            out3 = torch.stack([loss_output["loss"].detach(), loss_output["reconstruction_loss"].detach(),
+                                loss_output["kld_loss"].detach()])
+        scheduler.step()
+        total_step += 1
+        batch_size_all = batch_size_this_gpu * getattr(config, "world_size", world)
+        n_samples_seen += batch_size_all
+        loss_batch, loss_recon, loss_kld = out3.tolist()  # one D2H sync for the three .item() of train.py:672-674
+        loss_epoch += loss_batch
+        if epoch <= 1 and batch_idx == 0 and verbose:
+            print("stimuli.shape =", stimuli.shape)
+            print("logits.shape  =", reconstruction.shape)
+            print("loss =", loss_batch)
+        if batch_idx <= 2 or batch_idx % config.print_interval == 0 or batch_idx >= len(dataloader) - 1:
+            if getattr(config, "global_rank", 0) == 0:
+                print(
+                    f"Train Epoch:{epoch:4d}" + (f"/{n_epoch}" if n_epoch is not None else ""),
+                    f" Step:{batch_idx + 1:4d}/{len(dataloader)}",
+                    f" Loss:[F: {loss_batch:6.3f}, KL: {loss_kld:6.3f}]",
+                    f" LR: {scheduler.get_last_lr()[0]:.5f}",
+                    f" KL Weight: {model.kld_weight:.5f}",
+                )
+        if log_wandb and getattr(config, "global_rank", 0) == 0 and batch_idx % config.log_interval == 0:
+            wandb.log({
+                "training/stepwise/epoch": epoch,
+                "training/stepwise/epoch_progress": epoch - 1 + (batch_idx + 1) / len(dataloader),
+                "training/stepwise/n_samples_seen": n_samples_seen,
+                "training/stepwise/train/loss": loss_batch,
+                "training/stepwise/train/loss_recon": loss_recon,
+                "training/stepwise/train/loss_kld": loss_kld,
+                "training/stepwise/train/kld_weight": model.kld_weight,
+            }, step=total_step)
+    results = {"loss": loss_epoch / len(dataloader)}
+    return results, total_step, n_samples_seen
+
+
+class SyntheticPianorollLoader:
+    """Batches of the synthetic line/pianoroll distribution (data_generators.py:45-77), generated on the
+    device by the library (include/vae_step.h: vae_synth_pianoroll).  Yields (stimuli, y_true)."""
+
+    def __init__(self, batch_size: int, img_size: int, n_batches: int, seed: int = 0, device="cuda", pool: int = 0):
+        self.batch_size, self.img_size, self.n_batches, self.seed, self.device = batch_size, img_size, n_batches, seed, device
+        self.pool = pool
+        self._cache = {}
+
+    def __len__(self):
+        return self.n_batches
+
+    def batch(self, i: int):
+        from . import _lib
+        key = i % self.pool if self.pool else None
+        if key is not None and key in self._cache:
+            return self._cache[key]
+        x = torch.empty(self.batch_size, 1, self.img_size, self.img_size, device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().vae_synth_pianoroll(x.data_ptr(), self.batch_size, self.img_size,
+                                                  self.seed + (key if key is not None else i),
+                                                  torch.cuda.current_stream().cuda_stream), "vae_synth_pianoroll")
+        y = torch.zeros(self.batch_size, dtype=torch.long, device=self.device)
+        if key is not None:
+            self._cache[key] = (x, y)
+        return x, y
+
+    def __iter__(self):
+        for i in range(self.n_batches):
+            yield self.batch(i)
