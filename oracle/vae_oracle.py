@@ -385,6 +385,7 @@ def backward(p: dict, c: dict, kld_weight: float = 1.0) -> dict:
 
     def block_bwd(name, bn_name, da, transposed):
         dz = lrelu_bwd(c[name + ".z"], da)
+        g[name + ".dz"] = dz
         dy, dgam, dbet = bn_train_bwd(dz, p[bn_name + ".weight"], c[name + ".bn"])
         g[bn_name + ".weight"], g[bn_name + ".bias"] = dgam, dbet
         xin = c[name + ".in"]
@@ -401,6 +402,7 @@ def backward(p: dict, c: dict, kld_weight: float = 1.0) -> dict:
         da = block_bwd(name, name + ".1", da, True)
     B = da.shape[0]
     dd0 = da.reshape(B, -1)
+    g["__dd0"] = dd0
     g["decoder_input.weight"] = dd0.T @ c["zlat"]
     g["decoder_input.bias"] = dd0.sum(axis=0)
     dzlat = dd0 @ p["decoder_input.weight"]

@@ -47,6 +47,9 @@ def run(H, L, B, gen, dtype, seed=3, tr16=1):
     res["mu"] = rel(model._last["mu"].cpu().numpy(), c["mu"]); res["lv"] = rel(model._last["lv"].cpu().numpy(), c["lv"])
     res["z"] = rel(model._last["z"].cpu().numpy(), c["zlat"])
     s = int(round((c["zlat"] @ p["decoder_input.weight"].T).shape[1] // 256) ** 0.5)
+    res["dd0"] = rel(dbg(model, 17, (B, 256, s, s)), g["__dd0"].reshape(B, 256, s, s)) if "__dd0" in g else None
+    for i, n in enumerate(names):
+        if n + ".dz" in g: res[f"dz{i}"] = rel(dbg(model, 8 + i, g[n + ".dz"].shape), g[n + ".dz"])
     res["d0"] = rel(dbg(model, 16, (B, 256, s, s)), (c["zlat"] @ p["decoder_input.weight"].T + p["decoder_input.bias"]).reshape(B, 256, s, s))
     res["xhat"] = rel(xhat.cpu().numpy(), c["output"])
     res["loss"] = [out3.tolist(), [float(lo["loss"]), float(lo["reconstruction_loss"]), float(lo["kld_loss"])]]
@@ -62,8 +65,10 @@ if __name__ == "__main__":
     rc = _lib.lib().vae_selftest_tr16(torch.cuda.current_stream().cuda_stream)
     print("tr16 selftest rc", rc, _lib.lib().vae_last_error())
     allres = []
-    for cfg in [(32, 16, 4, False, "f32", 1), (32, 16, 32, False, "f32", 1), (64, 16, 4, True, "f32", 1),
-                (32, 16, 4, False, "bf16", 0), (32, 16, 4, False, "bf16", 1), (64, 16, 4, True, "bf16", 1), (128, 16, 2, True, "bf16", 1)]:
+    import ast
+    cfgs = ast.literal_eval(sys.argv[1]) if len(sys.argv) > 1 else [(32, 16, 4, False, "f32", 1), (32, 16, 33, False, "f32", 1), (64, 64, 8, True, "f32", 1),
+                (32, 16, 4, False, "bf16", 0), (32, 16, 4, False, "bf16", 1), (64, 16, 4, True, "bf16", 1), (128, 16, 2, True, "bf16", 1)]
+    for cfg in cfgs:
         try:
             r = run(*cfg[:5], tr16=cfg[5])
         except Exception as e:  # noqa

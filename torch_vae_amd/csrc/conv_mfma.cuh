@@ -296,6 +296,17 @@ template <typename T> struct WgradArgs {
 
 static constexpr int WG_KP = 64;  // low-res pixels per K tile
 
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+// k-major bf16 fragment from two transposed LDS reads (rows k..k+3 and k+4..k+7 of a [k][channel] image)
+__device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad1);
+    const s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, w);
+    return f;
+}
+
 template <typename T, int WA, int WB>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     const bool S_TWO = a.s_two != 0, G_TWO = a.g_two != 0;
@@ -370,15 +381,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
                 }
             } else {
                 if (a.use_tr16) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int k = ks * 16 + 8 * (g4 >> 1) + 4 * half + q;
-                        const char* ad = stile + k * SPITCH + (wa * 32 + 16 * (g4 & 1) + 4 * p) * 2;
-                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) af.v[4 * half + e] = __builtin_bit_cast(bf16, v[e]);
-                        growbase[half] = ((k >> (a.lth + a.ltw)) * PH + 2 * ((k >> a.ltw) & (th - 1))) * PW + 2 * (k & (tw - 1));
-                    }
+                    const int k0 = ks * 16 + 8 * (g4 >> 1) + q, k1 = k0 + 4;
+                    const int col = (wa * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                    af = frag_tr16(stile + k0 * SPITCH + col, stile + k1 * SPITCH + col);
+                    growbase[0] = ((k0 >> (a.lth + a.ltw)) * PH + 2 * ((k0 >> a.ltw) & (th - 1))) * PW + 2 * (k0 & (tw - 1));
+                    growbase[1] = ((k1 >> (a.lth + a.ltw)) * PH + 2 * ((k1 >> a.ltw) & (th - 1))) * PW + 2 * (k1 & (tw - 1));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -398,13 +405,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
                         bf.v[j] = *reinterpret_cast<const float*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 4);
                 } else {
                     if (a.use_tr16) {
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const char* ad = gtile + (growbase[half] + toff) * GPITCH + (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
-                            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) bf.v[4 * half + e] = __builtin_bit_cast(bf16, v[e]);
-                        }
+                        const int col = (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                        bf = frag_tr16(gtile + (growbase[0] + toff) * GPITCH + col, gtile + (growbase[1] + toff) * GPITCH + col);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)

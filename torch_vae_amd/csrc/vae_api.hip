@@ -726,14 +726,53 @@ __global__ void selftest_tr16_kernel(int* bad) {
     }
     if (nbad) atomicAdd(bad, nbad);
 }
+// Kernel-shaped variant: rows at an arbitrary pitch/base, row gather at stride (the wgrad G operand).
+__global__ void selftest_tr16b_kernel(int* bad, int* info, int pitch, int base, int rowstride) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int lane = threadIdx.x;
+    short* t = reinterpret_cast<short*>(sm);
+    for (int i = lane; i < 8192; i += 64) t[i] = (short)(i * 7 + 3);
+    __syncthreads();
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, r = lane & 31, h = lane >> 5;
+    int nbad = 0;
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k = ks * 16 + 8 * (g4 >> 1) + 4 * half + q;
+            const char* ad = sm + base + (k * rowstride) * pitch + (16 * (g4 & 1) + 4 * p) * 2;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = ks * 16 + 8 * h + 4 * half + e;
+                const short want = *reinterpret_cast<const short*>(sm + base + (kk * rowstride) * pitch + r * 2);
+                if (v[e] != want) { if (nbad == 0 && lane < 64) { info[lane * 4] = ks * 100 + half * 10 + e; info[lane * 4 + 1] = v[e]; info[lane * 4 + 2] = want; } ++nbad; }
+            }
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
 extern "C" int vae_selftest_tr16(vae_stream_t stream) {
-    int* d = nullptr; int h = 0;
-    HIP_CHECK_RET(hipMalloc(&d, 4));
-    HIP_CHECK_RET(hipMemsetAsync(d, 0, 4, (hipStream_t)stream));
+    int* d = nullptr; int h[1 + 256];
+    HIP_CHECK_RET(hipMalloc(&d, sizeof(h)));
+    const int cfgs[5][3] = {{64, 0, 1}, {144, 1536, 1}, {80, 768, 1}, {144, 1536, 2}, {80, 768, 3}};
+    std::string msg;
+    HIP_CHECK_RET(hipMemsetAsync(d, 0, sizeof(h), (hipStream_t)stream));
     hipLaunchKernelGGL(selftest_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
-    HIP_CHECK_RET(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK_RET(hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+    if (h[0]) msg += "basic:" + std::to_string(h[0]) + " ";
+    for (int c = 0; c < 5; ++c) {
+        HIP_CHECK_RET(hipMemsetAsync(d, 0, sizeof(h), (hipStream_t)stream));
+        hipLaunchKernelGGL(selftest_tr16b_kernel, dim3(1), dim3(64), 16384, (hipStream_t)stream, d, d + 1, cfgs[c][0], cfgs[c][1], cfgs[c][2]);
+        HIP_CHECK_RET(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+        if (h[0]) {
+            msg += "cfg" + std::to_string(c) + ":" + std::to_string(h[0]) + "[";
+            for (int l = 0; l < 64; l += 9) msg += "L" + std::to_string(l) + ":" + std::to_string(h[1 + l * 4]) + "," + std::to_string(h[2 + l * 4]) + "," + std::to_string(h[3 + l * 4]) + " ";
+            msg += "] ";
+        }
+    }
     (void)hipFree(d);
-    if (h) { char buf[64]; snprintf(buf, sizeof(buf), "%d mismatching elements", h); return vae_set_error("ds_read_b64_tr_b16 self-test", buf); }
+    if (!msg.empty()) return vae_set_error("ds_read_b64_tr_b16 self-test", msg.c_str());
     return 0;
 }

@@ -407,9 +407,7 @@ class VanillaVAE(nn.Module):
         else:
             xhat, mu, lv, z, pre = self._run_forward(x, eps, train=self.training)
             handle = None
-        self._last["handle"] = handle
-        self._last["out_id"] = id(xhat)
-        self._last["out_ref"] = xhat
+        self._last.update(handle=handle, out_ref=xhat, mu=mu, lv=lv, z=z)
         encoding = EncoderOutput(mu=mu, log_var=lv, pre_latents=pre)
         return ModelOutput(output=xhat, input=x, encoded=encoding, latents=z)
 
