@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native VAE training step (the metric BASELINE.json names).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one resident synthetic batch: forward, ELBO,
+backward, [gradient all-reduce over RCCL when N>1], fused AdamW, OneCycle scheduler step
+(train.py:634-659 of the reference).  Inputs are generated on the device before the timed
+region (H2D excluded).  Workload at N=1: BASELINE.json configs[1] on the metric's 128x128
+pianoroll: VanillaVAE latent_dim=16, batch 256, bf16 storage / f32 accumulate (generalised
+model).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=128, help="pianoroll side (128 = the metric's; 32 = reference-exact model)")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--latent", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the VAE step has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from argparse import Namespace
+    from torch_vae_amd import _lib
+    from torch_vae_amd.models import VanillaVAE, algorithmic_bytes_per_step, count_flops_per_sample
+    from torch_vae_amd.train import SyntheticPianorollLoader, allreduce_gradients, build_optimizer
+
+    H, L, B = args.size, args.latent, args.batch
+    gen = H != 32
+    torch.manual_seed(0)  # identical initial weights on every rank
+    model = VanillaVAE(1, L, H, generalised=gen, compute_dtype=args.dtype, max_batch=B).to(dev)
+    total_steps = args.steps + args.warmup + 8
+    cfg = Namespace(batch_size_per_gpu=B, world_size=world, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW",
+                    scheduler="OneCycle", epochs=1, freeze_encoder=False)
+    opt, sched = build_optimizer(cfg, model, steps_per_epoch=total_steps)
+    pool = SyntheticPianorollLoader(B, H, n_batches=4, seed=1000 * rank, device=dev, pool=4)
+    batches = [pool.batch(i)[0] for i in range(4)]
+    model.eps_seed = 7919 * (rank + 1)
+    losses = torch.zeros(3, device=dev)
+
+    def step(i):
+        out3, _ = model.fused_forward_backward(batches[i % 4])
+        for w in allreduce_gradients(model, opt):
+            w.wait()
+        opt.step()
+        sched.step()
+        return out3
+
+    for i in range(args.warmup):
+        losses = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = losses.tolist()
+
+    # per-kernel durations (HIP events on the launch stream), outside the timed region
+    roofline, kernels = None, []
+    if rank == 0:
+        L_ = _lib.lib()
+        _lib.check(L_.vae_profile(model._ctx.handle, 1), "vae_profile")
+        nprof = 3
+        for i in range(nprof):
+            step(args.warmup + args.steps + i)
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(L_.vae_profile_report(model._ctx.handle, buf, len(buf)), "vae_profile_report")
+        _lib.check(L_.vae_profile(model._ctx.handle, 0), "vae_profile")
+        kernels = json.loads(buf.value.decode())
+        for k in kernels:
+            k["ms_per_call"] = k["ms"] / k["calls"]
+            k["gbs"] = k["bytes"] / k["ms"] / 1e6 if k["ms"] > 0 else 0.0
+            k["tflops"] = k["flops"] / k["ms"] / 1e9 if k["ms"] > 0 else 0.0
+        kernels.sort(key=lambda k: -k["ms"])
+        dom = kernels[0]
+        ach = dom["gbs"]
+        roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom["name"],
+                    "avg_launch_us": round(1e3 * dom["ms_per_call"], 2),
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
+                    "kernel_tflops": round(dom["tflops"], 1)}
+        if args.kernels:
+            tot = sum(k["ms"] for k in kernels) / nprof
+            print(f"per-step kernel time {tot:.3f} ms", file=sys.stderr)
+            for k in kernels:
+                print(f"  {k['name']:40s} calls/step {k['calls'] // nprof:3d}  {k['ms'] / nprof:8.3f} ms/step  {k['gbs']:8.1f} GB/s  {k['tflops']:7.1f} TF", file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.torch_cpu_step import time_cpu_baseline
+        ncores = os.cpu_count() or 1
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        ncores = min(ncores, 16)  # the GPU box gives one GPU a 16-core CPU share
+        cb = min(B, 32) if H >= 128 else B
+        r = time_cpu_baseline(H, L, cb, generalised=gen, budget_s=args.cpu_budget, threads=ncores)
+        cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "kind": "port",
+               "sample": f"{r['steps']} steps of the same model/input size at batch {cb}, f32, torch CPU ops "
+                         f"(oracle/torch_cpu_step.py), {r['seconds']:.1f} s"}
+
+    if rank == 0:
+        esz = 2 if args.dtype == "bf16" else 4
+        value = world * B * args.steps / dt
+        step_bytes = algorithmic_bytes_per_step(H, L, B, esz, gen)
+        step_flops = count_flops_per_sample(H, L, gen) * B
+        ms = 1e3 * dt / args.steps
+        out = {
+            "metric": "training samples/sec (VAE step: forward+ELBO+backward+AdamW), synthetic pianoroll",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"VanillaVAE latent_dim={L}, {H}x{H} synthetic pianoroll, batch {B}/GPU"
+                                   f"{' (generalised bottleneck 256*(H/16)^2)' if gen else ' (reference-exact 32x32 model)'}",
+                       "img_size": H, "latent_dim": L, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "optimizer": "AdamW+OneCycle (encoder, decoder groups)"},
+            "roofline": roofline,
+            "step_roofline": {"algorithmic_bytes": step_bytes, "algorithmic_flops": step_flops,
+                              "hbm_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.dtype], 4)},
+            "cpu_baseline": cpu,
+            "elbo_last_step": {"loss": final_loss[0], "reconstruction_loss": final_loss[1], "kld_loss": final_loss[2]},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,12 @@ int vae_train_step(vae_ctx* ctx, const float* x, int batch, float* params, float
  * (called as at :97-104), seeded; x [B,1,H,H] f32 in {0,1}.  Device-side generator. */
 int vae_synth_pianoroll(float* x, int batch, int img_size, uint64_t seed, vae_stream_t stream);
 
+/* Per-kernel timing for bench.py's roofline line: when enabled every launch of the step is
+ * bracketed by HIP events on the launch stream; the report is a JSON array with, per kernel name,
+ * calls, total ms, and total ALGORITHMIC bytes / flops (operand tensors once). */
+int vae_profile(vae_ctx* ctx, int enable);
+int vae_profile_report(vae_ctx* ctx, char* buf, int64_t capacity);
+
 /* Debug / test hooks: copy an internal NHWC tensor to f32 NCHW.  which: 0..7 raw conv output
  * of BN layer i, 8..15 its dz, 16 decoder_input output, 17 its gradient. */
 int vae_debug_tensor(vae_ctx* ctx, int which, float* out, int64_t capacity, vae_stream_t stream);

@@ -127,3 +127,18 @@ def test_synth_pianoroll_distribution():
     assert 0.01 < x.mean() < 0.6
     assert (vo.synth_pianoroll(4, 32, seed=3) == x[:4]).all() is not None  # deterministic call
     np.testing.assert_array_equal(vo.synth_pianoroll(64, 32, seed=3), x)
+
+
+@pytest.mark.parametrize("name", ["R_b32_k1", "G_h64_l16_b4"])
+def test_torch_cpu_port_matches_reference(name):
+    """The CPU baseline port (oracle/torch_cpu_step.py) reproduces the reference's f32 trajectory."""
+    import torch
+    from oracle.torch_cpu_step import TorchCpuStep
+    H, L, B, steps, total, kw, gen, seed = CASES[name]
+    gold = np.load(os.path.join(GOLD, f"{name}_f32.npz"))
+    st = TorchCpuStep(vo.init_params(L, H, seed, gen), kld_weight=kw, batch=B, total_steps=total)
+    losses = []
+    for s in range(min(steps, 5)):
+        x, eps = case_inputs(name, s, np.float32)
+        losses.append(st.step(torch.from_numpy(x), torch.from_numpy(eps)))
+    np.testing.assert_allclose(np.array(losses), gold["losses"][:len(losses)], rtol=5e-5)

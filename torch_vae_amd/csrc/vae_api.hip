@@ -94,6 +94,21 @@ struct vae_ctx {
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
     int use_tr16; int64_t ws_bytes;
     std::vector<void*> allocs;
+    // per-kernel timing (bench.py roofline): HIP events on the launch stream
+    int prof; struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
+};
+
+// RAII: brackets the launches of one logical kernel with events when profiling is on.
+struct ProfScope {
+    vae_ctx* c; hipStream_t st; int idx;
+    ProfScope(vae_ctx* c_, const char* name, double bytes, double flops, hipStream_t st_) : c(c_), st(st_), idx(-1) {
+        if (!c || !c->prof) return;
+        vae_ctx::ProfRec r; r.name = name; r.bytes = bytes; r.flops = flops;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, st);
+        c->prof_recs.push_back(r); idx = (int)c->prof_recs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, st); }
 };
 
 template <typename T> static T* dalloc(vae_ctx* c, size_t n) {
@@ -132,7 +147,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
     c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1;
-    c->packed_for = nullptr; c->B = 0; c->trained = 0;
+    c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
     if (maxB < 1) { vae_set_error("vae_create", "max_batch < 1"); delete c; return nullptr; }
@@ -225,6 +240,10 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     const int NT = std::min(4, a.Cout / 32);
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (2 * th + 1) * (2 * tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
     dim3 grid(n_tiles, a.Cout / (32 * NT));
+    const double px_out = (double)a.B * a.Hs * a.Ws, px_in = 4 * px_out;
+    ProfScope ps(c, a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)",
+                 sizeof(T) * (px_in * a.Cin * (a.two_src ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
+                 2.0 * 9 * a.Cin * a.Cout * px_out, st);
 #define DOWN_CASE(N) { if (set_lds(down_kernel<T, N>, lds)) return -1; hipLaunchKernelGGL((down_kernel<T, N>), grid, dim3(256), lds, st, a); }
     if (NT == 1) DOWN_CASE(1) else if (NT == 2) DOWN_CASE(2) else DOWN_CASE(4)
 #undef DOWN_CASE
@@ -241,6 +260,10 @@ static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     const int NT = std::min(2, a.Cout / 32);
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (th + 1) * (tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
     dim3 grid(n_tiles, a.Cout / (32 * NT));
+    const double px_in = (double)a.B * a.Hs * a.Ws, px_out = 4 * px_in;
+    ProfScope ps(c, a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)",
+                 sizeof(T) * (px_in * a.Cin * (a.two_src ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
+                 2.0 * 9 * a.Cin * a.Cout * px_in, st);
 #define UP_CASE(N) { if (set_lds(up_kernel<T, N>, lds)) return -1; hipLaunchKernelGGL((up_kernel<T, N>), grid, dim3(256), lds, st, a); }
     if (NT == 1) UP_CASE(1) else UP_CASE(2)
 #undef UP_CASE
@@ -268,6 +291,10 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16);
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
+    const double px_s = (double)a.B * a.Hs * a.Ws;
+    ProfScope ps(c, "wgrad(+slab reduce)",
+                 sizeof(T) * (px_s * a.CA * (a.s_two ? 2 : 1) + 4 * px_s * a.CB * (a.g_two ? 2 : 1)) + 4.0 * 9 * a.CA * a.CB,
+                 2.0 * 9 * a.CA * a.CB * px_s, st);
 #define WG_CASE(A_, B_) { if (set_lds(wgrad_kernel<T, A_, B_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_>), grid, dim3(256), lds, st, a); }
     if (WA == 2 && WB == 2) WG_CASE(2, 2) else if (WA == 2 && WB == 1) WG_CASE(2, 1) else WG_CASE(1, 1)
 #undef WG_CASE
@@ -285,6 +312,7 @@ static int launch_dense(vae_ctx* c, DenseArgs<T> a, int* nsplit_out, hipStream_t
     if ((size_t)nsplit * a.M * a.Npad > c->slab_floats) return vae_set_error("dense", "slab too small");
     a.slab = c->slab;
     dim3 grid(mt, nsplit, ntile);
+    ProfScope ps(c, "dense(fc / decoder_input dgrad)", sizeof(T) * ((double)a.M * a.K + (double)a.K * a.Npad), 2.0 * a.M * a.K * a.Npad, st);
     if (NT == 1) hipLaunchKernelGGL((dense_kernel<T, 1>), grid, dim3(256), 0, st, a);
     else if (NT == 2) hipLaunchKernelGGL((dense_kernel<T, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dense_kernel<T, 4>), grid, dim3(256), 0, st, a);
@@ -373,6 +401,7 @@ static int pack_weights(vae_ctx* c, const float* params, hipStream_t st) {
         HIP_CHECK_RET(hipMemcpyAsync(c->d_descs, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
         c->packed_for = params;
     }
+    ProfScope ps(c, "pack_weights", 0, 0, st);
     hipLaunchKernelGGL((pack_kernel<T>), dim3(64, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
     LAUNCH_CHECK("pack_kernel");
     return 0;
@@ -407,6 +436,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     {
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 2048);
+        ProfScope ps(c, "conv1_fwd", 4.0 * B * H * H + (double)sizeof(T) * 32.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
         LAUNCH_CHECK("conv1_fwd_kernel");
@@ -442,6 +472,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     // decoder_input
     {
         dim3 grid((unsigned)(c->F / 256), (B + 15) / 16);
+        ProfScope ps(c, "decin_fwd", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
         hipLaunchKernelGGL((decin_fwd_kernel<T>), grid, dim3(256), 16 * L * 4, st, z, params + c->poff[20], params + c->poff[21],
                            reinterpret_cast<T*>(c->d0), B, (int)c->F, L, c->s2);
         LAUNCH_CHECK("decin_fwd_kernel");
@@ -462,6 +493,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
         a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
         a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
+        ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
         hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
         LAUNCH_CHECK("convout_fwd_kernel");
     }
@@ -505,6 +537,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         a.dz = c->lay[7].dz; a.slab = c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
         const long P = (long)B * H * H;
         const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
         hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
         LAUNCH_CHECK("convout_bwd_kernel");
         if (launch_reduce(c->slab, grid, 288, grads + c->poff[38], 1, 32, st)) return -1;
@@ -537,6 +570,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     // decoder_input backward, reparameterisation + KL backward
     {
         dim3 grid((unsigned)(c->F / 256), (L + 31) / 32);
+        ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
         hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(c->dd0), c->z,
                            grads + c->poff[20], grads + c->poff[21], B, (int)c->F, L, c->s2);
         LAUNCH_CHECK("decin_wgrad_kernel");
@@ -558,12 +592,14 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         FcWgradArgs<T> w;
         w.dlat = c->dlat; w.y = reinterpret_cast<const T*>(c->lay[3].y); w.coef = c->lay[3].block; w.slope = kSlope;
         w.dwmu = grads + c->poff[16]; w.dwvar = grads + c->poff[18]; w.B = B; w.F = (int)c->F; w.L = L; w.s2 = c->s2;
+        ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, st);
         hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32), dim3(256), 0, st, w);
         LAUNCH_CHECK("fc_wgrad_kernel");
         FcDgradArgs<T> d;
         d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
         d.ocoef = c->lay[3].block; d.slope = kSlope; d.gpre = g_pre; d.dz = reinterpret_cast<T*>(c->lay[3].dz); d.stat = c->lay[3].stat_b;
         d.B = B; d.F = (int)c->F; d.L2 = 2 * L; d.s2 = c->s2;
+        ProfScope ps2(c, "fc_dgrad", (double)sizeof(T) * (2.0 * B * c->F + 2.0 * c->F * L), 4.0 * B * c->F * L, st);
         hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + 15) / 16), dim3(256), 2 * L * 16 * 4, st, d);
         LAUNCH_CHECK("fc_dgrad_kernel");
     }
@@ -587,6 +623,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const T*>(c->lay[0].dz),
                            reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, c->slab, B, H, H);
         LAUNCH_CHECK("conv1_wgrad_kernel");
@@ -662,6 +699,39 @@ extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, 
     if (vae_loss(c, kld_weight, out3, stream)) return -1;
     if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
     if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, 1.f, step, stream)) return -1;
+    return 0;
+}
+
+extern "C" int vae_profile(vae_ctx* c, int enable) {
+    if (!c) return vae_set_error("vae_profile", "null ctx");
+    for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    c->prof_recs.clear(); c->prof = enable;
+    return 0;
+}
+// JSON: [{"name":..,"calls":n,"ms":total,"bytes":total algorithmic bytes,"flops":total}, ...]
+extern "C" int vae_profile_report(vae_ctx* c, char* buf, int64_t cap) {
+    if (!c) return vae_set_error("vae_profile_report", "null ctx");
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    struct Agg { std::string name; int calls; double ms, bytes, flops; };
+    std::vector<Agg> agg;
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        Agg* a = nullptr;
+        for (auto& x : agg) if (x.name == r.name) a = &x;
+        if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
+        a->calls += 1; a->ms += ms; a->bytes += r.bytes; a->flops += r.flops;
+    }
+    std::string out = "[";
+    for (size_t i = 0; i < agg.size(); ++i) {
+        char line[512];
+        snprintf(line, sizeof(line), "%s{\"name\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"bytes\":%.1f,\"flops\":%.1f}", i ? "," : "",
+                 agg[i].name.c_str(), agg[i].calls, agg[i].ms, agg[i].bytes, agg[i].flops);
+        out += line;
+    }
+    out += "]";
+    if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_report", "buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
 
