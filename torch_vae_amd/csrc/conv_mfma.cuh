@@ -33,7 +33,12 @@ template <typename T> struct ConvArgs {
     int B, Hs, Ws, Cin, Cout;                                      // Hs,Ws: low-res side (down: output, up: input)
     int lth, ltw, lTB, tiles_x, tiles_y;
     int two_src, epi;                                              // runtime: gradient-operand load / epilogue kind
+    unsigned m_pp, m_pw, m_tx, m_txy;                              // fastdiv magics: PP, PW, tiles_x, tiles_x*tiles_y
 };
+
+// x / d for small x via one mul_hi: m = ceil(2^32 / d), exact for x, d < 2^16
+__device__ __forceinline__ int fastdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }  // m == 0 encodes d == 1
+static inline unsigned fastdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
 
 static constexpr int PATCH_PITCH = 80;  // bytes per staged pixel: 64 B of channels + 16 B pad (LDS bank spread)
 
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
     float* red = reinterpret_cast<float*>(patch + npix * PATCH_PITCH);
 
     const int tile = blockIdx.x;
-    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+    const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
     const int b0 = bt << a.lTB, oy0 = ty << a.lth, ox0 = tx << a.ltw, n0 = blockIdx.y * 32 * NT;
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
         __syncthreads();
         for (int it = tid; it < npix * 4; it += 256) {
             const int pix = it >> 2, q = it & 3;
-            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = 2 * oy0 - 1 + py, ix = 2 * ox0 - 1 + px;
             Vec16<T> v = zero_vec16<T>();
             if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
     float* red = reinterpret_cast<float*>(patch + npix * PATCH_PITCH);
 
     const int tile = blockIdx.x;
-    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+    const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
     const int b0 = bt << a.lTB, iy0 = ty << a.lth, ix0 = tx << a.ltw, n0 = blockIdx.y * 32 * NT;
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
         __syncthreads();
         for (int it = tid; it < npix * 4; it += 256) {
             const int pix = it >> 2, q = it & 3;
-            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = iy0 + py, ix = ix0 + px;
             Vec16<T> v = zero_vec16<T>();
             if (b < a.B && iy < Hs && ix < Ws) {
@@ -287,11 +292,12 @@ __global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
 template <typename T> struct WgradArgs {
     const T* s0; const T* s1; const float* scoef; float sslope;  // low-res operand  [B,Hs,Ws,CA]
     const T* g0; const T* g1; const float* gcoef; float gslope;  // high-res operand [B,2Hs,2Ws,CB]
-    float* slab;                                                 // [nsplit*WK][9][CA][CB]
+    float* slab;                                                 // [nsplit][9][CA][CB]
     int s_two, g_two;
     int B, Hs, Ws, CA, CB;
     int lth, ltw, lTB, tiles_x, tiles_y, n_tiles, tiles_per_split;
     int use_tr16;
+    unsigned m_pp, m_pw, m_tx, m_txy;
 };
 
 static constexpr int WG_KP = 64;  // low-res pixels per K tile
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     const int t_begin = blockIdx.x * a.tiles_per_split;
     const int t_end = min(a.n_tiles, t_begin + a.tiles_per_split);
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, bt = tile / (a.tiles_x * a.tiles_y);
+        const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
         __syncthreads();
         for (int it = tid; it < WG_KP * SCH; it += 256) {
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
         }
         for (int it = tid; it < npix * GCH; it += 256) {
             const int pix = it / GCH, qq = it - pix * GCH;
-            const int img = pix / PP, rem = pix - img * PP, py = rem / PW, px = rem - py * PW;
+            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
             Vec16<T> v = zero_vec16<T>();
             if (b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg) {
@@ -418,30 +424,68 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
         }
     }
 
+    // combine the WK wave-level K splits through LDS (staging area is free now), one tap at a time
+    if constexpr (WK > 1) {
+        float* xch = reinterpret_cast<float*>(stile);   // [(WK-1)*WA*WB waves][16][64]
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            if (wk > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xch[(((wk - 1) * WA * WB + wb * WA + wa) * 16 + i) * 64 + lane] = acc[t][i];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int w = 0; w < WK - 1; ++w)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += xch[((w * WA * WB + wb * WA + wa) * 16 + i) * 64 + lane];
+            }
+        }
+    }
     // partial slab: rows = low-res-side channel (a), lanes = high-res-side channel (b)
-    const size_t slab_id = (size_t)blockIdx.x * WK + wk;
+    if (wk == 0) {
+        const size_t slab_id = blockIdx.x;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ca = a0 + wa * 32 + acc_row(i, lane), cb = bc0 + wb * 32 + r;
-            a.slab[((slab_id * 9 + t) * CA + ca) * CB + cb] = acc[t][i];
+            for (int i = 0; i < 16; ++i) {
+                const int ca = a0 + wa * 32 + acc_row(i, lane), cb = bc0 + wb * 32 + r;
+                a.slab[((slab_id * 9 + t) * CA + ca) * CB + cb] = acc[t][i];
+            }
         }
     }
 }
 
 // out[(a*CB+b)*9+t] = sum_s slab[s][t][a][b]   (CA>0: conv weight layout [A][B][3][3])
 // out[j]            = sum_s slab[s][j]          (CA==0)
-__global__ void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out, int CA, int CB) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// block = 64 outputs x 4 slab groups; each thread keeps 8 independent loads in flight.
+__global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n,
+                                                          float* __restrict__ out, int CA, int CB) {
+    __shared__ float part[4][64];
+    const int jl = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + jl;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + j];
-    if (CA > 0) {
-        const int t = j / (CA * CB), rem = j - t * CA * CB;
-        out[(size_t)rem * 9 + t] = s;
-    } else {
-        out[j] = s;
+    if (j < n) {
+        int k = g;
+        for (; k + 28 < nslab; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + 4 * u) * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nslab; k += 4) s += slab[(size_t)k * n + j];
+    }
+    part[g][jl] = s;
+    __syncthreads();
+    if (g == 0 && j < n) {
+        s = part[0][jl] + part[1][jl] + part[2][jl] + part[3][jl];
+        if (CA > 0) {
+            const int t = j / (CA * CB), rem = j - t * CA * CB;
+            out[(size_t)rem * 9 + t] = s;
+        } else {
+            out[j] = s;
+        }
     }
 }
 

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                         double* __restrict__ stat, int B, int H, int W) {
     __shared__ float red[4][4][16];
     const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long P = (long)B * Ho * Wo;
+    const int Ho = H >> 1, Wo = W >> 1, lw = 31 - __builtin_clz(Wo), lh = 31 - __builtin_clz(Ho);
+    const int P = B * Ho * Wo;
     float wr[8][9], br[8], s1[8], s2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(cg * 8 + c) * 9 + t];
     }
-    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
-        const int ox = p % Wo, oy = (p / Wo) % Ho; const long b = p / ((long)Wo * Ho);
+    for (int p = blockIdx.x * 64 + slot; p < P; p += gridDim.x * 64) {
+        const int ox = p & (Wo - 1), oy = (p >> lw) & (Ho - 1); const size_t b = p >> (lw + lh);
         float xv[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int t = 0; t < 9; ++t) acc += wr[c][t] * xv[t];
             o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
         }
-        store8<T>(y + p * 32 + cg * 8, o);
+        store8<T>(y + (size_t)p * 32 + cg * 8, o);
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
                                                           float* __restrict__ slab, int B, int H, int W) {
     __shared__ float red[4][4][72];
     const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long P = (long)B * Ho * Wo;
+    const int Ho = H >> 1, Wo = W >> 1, lw = 31 - __builtin_clz(Wo), lh = 31 - __builtin_clz(Ho);
+    const int P = B * Ho * Wo;
     float p0[8], p1[8], p2[8], acc[8][9];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -105,15 +105,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
     }
-    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
-        const int ox = p % Wo, oy = (p / Wo) % Ho; const long b = p / ((long)Wo * Ho);
+    for (int p = blockIdx.x * 64 + slot; p < P; p += gridDim.x * 64) {
+        const int ox = p & (Wo - 1), oy = (p >> lw) & (Ho - 1); const size_t b = p >> (lw + lh);
         float xv[9], dv[8], yv[8];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
             xv[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(b * H + iy) * W + ix] : 0.f;
         }
-        load8<T>(dz + p * 32 + cg * 8, dv); load8<T>(y + p * 32 + cg * 8, yv);
+        load8<T>(dz + (size_t)p * 32 + cg * 8, dv); load8<T>(y + (size_t)p * 32 + cg * 8, yv);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float g = dv[c] * p0[c] + yv[c] * p1[c] + p2[c];
@@ -257,7 +257,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
     __shared__ float red[4][4][89];
     const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
-    const long P = (long)a.B * a.H * a.W;
+    const int P = a.B * a.H * a.W, lw = 31 - __builtin_clz(a.W), lh = 31 - __builtin_clz(a.H);
     const T* yf = reinterpret_cast<const T*>(a.yf);
     T* dzp = reinterpret_cast<T*>(a.dz);
     const float gs = a.gscale ? a.gscale[0] : 1.f;
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) { wr[c][t] = a.wt[t * 32 + ch]; dw[c][t] = 0.f; }
     }
-    for (long p = (long)blockIdx.x * 64 + slot; p < P; p += (long)gridDim.x * 64) {
-        const int x = p % a.W, y = (p / a.W) % a.H; const long b = p / ((long)a.W * a.H);
+    for (int p = blockIdx.x * 64 + slot; p < P; p += gridDim.x * 64) {
+        const int x = p & (a.W - 1), y = (p >> lw) & (a.H - 1); const size_t b = p >> (lw + lh);
         float dl[9], yv[8], o[8];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
             dl[t] = (qy >= 0 && qy < a.H && qx >= 0 && qx < a.W) ? a.dlogit[(b * a.H + qy) * a.W + qx] * gs : 0.f;
         }
         if (cg == 0) sdl += dl[4];
-        load8<T>(yf + p * 32 + cg * 8, yv);
+        load8<T>(yf + (size_t)p * 32 + cg * 8, yv);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float z = yv[c] * sc[c] + sh[c];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
             const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
             o[c] = dzv; s1[c] += dzv; s2[c] += dzv * (yv[c] * is[c] + xm[c]);
         }
-        store8<T>(dzp + p * 32 + cg * 8, o);
+        store8<T>(dzp + (size_t)p * 32 + cg * 8, o);
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -389,17 +389,22 @@ struct LatentFwdArgs {
     float* mu; float* lv; float* z; double* accum;  // accum[1] += sum(1 + lv - mu^2 - exp(lv))
     int B, L;
 };
-__global__ void latent_fwd_kernel(LatentFwdArgs a) {
+__global__ void latent_fwd_kernel(LatentFwdArgs a) {   // 8 lanes per (b,l): split-K slabs summed in parallel
     __shared__ float wred[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
     float term = 0.f;
-    if (i < a.B * a.L) {
-        const int b = i / a.L, l = i % a.L;
-        float m = a.bmu[l], v = a.bvar[l];
-        for (int s = 0; s < a.nslab; ++s) {
+    const bool ok = i < a.B * a.L;
+    const int b = ok ? i / a.L : 0, l = ok ? i % a.L : 0;
+    float m = 0.f, v = 0.f;
+    if (ok)
+        for (int s = sub; s < a.nslab; s += 8) {
             m += a.slab[((size_t)s * a.B + b) * a.npad + l];
             v += a.slab[((size_t)s * a.B + b) * a.npad + a.L + l];
         }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { m += __shfl_xor(m, o, 64); v += __shfl_xor(v, o, 64); }
+    if (ok && sub == 0) {
+        m += a.bmu[l]; v += a.bvar[l];
         const float sd = expf(0.5f * v);                      // models.py:181
         a.mu[i] = m; a.lv[i] = v; a.z[i] = a.eps[i] * sd + m;  // models.py:183
         term = 1.f + v - m * m - expf(v);                     // models.py:214
@@ -440,12 +445,17 @@ struct LatentBwdArgs {
     float* dlat;                          // [B][2L]: dmu | dlv
     int B, L; float kld_weight; int add_kl;
 };
-__global__ void latent_bwd_kernel(LatentBwdArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * a.L) return;
-    const int b = i / a.L, l = i % a.L;
-    float d = a.gz ? a.gz[i] : 0.f;
-    for (int s = 0; s < a.nslab; ++s) d += a.slab[((size_t)s * a.B + b) * a.npad + l];
+__global__ void latent_bwd_kernel(LatentBwdArgs a) {   // 8 lanes per (b,l)
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool ok = i < a.B * a.L;
+    const int b = ok ? i / a.L : 0, l = ok ? i % a.L : 0;
+    float d = 0.f;
+    if (ok)
+        for (int s = sub; s < a.nslab; s += 8) d += a.slab[((size_t)s * a.B + b) * a.npad + l];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) d += __shfl_xor(d, o, 64);
+    if (!ok || sub != 0) return;
+    if (a.gz) d += a.gz[i];
     const float gs = a.gscale ? a.gscale[0] : 1.f;
     const float m = a.mu[i], v = a.lv[i], sd = expf(0.5f * v);
     float dmu = d, dlv = d * a.eps[i] * sd * 0.5f;
@@ -457,13 +467,13 @@ __global__ void latent_bwd_kernel(LatentBwdArgs a) {
     if (a.glv) dlv += a.glv[i];
     a.dlat[(size_t)b * 2 * a.L + l] = dmu; a.dlat[(size_t)b * 2 * a.L + a.L + l] = dlv;
 }
-// column sums of dlat -> fc_mu.bias / fc_var.bias gradients
+// column sums of dlat -> fc_mu.bias / fc_var.bias gradients; one wave per column
 __global__ void colsum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ o0, float* __restrict__ o1, int split) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+    const int j = blockIdx.x;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += m[(size_t)r * cols + j];
-    if (j < split) o0[j] = s; else o1[j - split] = s;
+    for (int r = threadIdx.x; r < rows; r += 64) s += m[(size_t)r * cols + j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) { if (j < split) o0[j] = s; else o1[j - split] = s; }
 }
 
 // f' (NHWC flatten: pix*256 + c) -> reference flatten index c*s2 + pix (models.py:133)
@@ -553,14 +563,19 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
         }
         __syncthreads();
         const int nb = min(BC, a.B - bc);
-        for (int bb = 0; bb < nb; ++bb) {
-            const float av = leaky(tofloat(a.y[(size_t)(bc + bb) * a.F + fp]) * sc + sh, a.slope);
+        for (int bb = 0; bb < nb; bb += 8) {   // 8 independent loads in flight per thread
+            float av[8];
 #pragma unroll
-            for (int q = 0; q < JT / 4; ++q) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[bb * JT + q * 4]);
+            for (int u = 0; u < 8; ++u)
+                av[u] = (bb + u < nb) ? leaky(tofloat(a.y[(size_t)(bc + bb + u) * a.F + fp]) * sc + sh, a.slope) : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * av;
-            }
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < JT / 4; ++q) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[(bb + u) * JT + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * av[u];
+                }
         }
     }
     const int fr = fref_of(fp, a.s2);
@@ -617,14 +632,19 @@ __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ 
         }
         __syncthreads();
         const int nb = min(BC, B - bc);
-        for (int bb = 0; bb < nb; ++bb) {
-            const float g = tofloat(dd0[(size_t)(bc + bb) * F + fp]);
-            sb += g;
+        for (int bb = 0; bb < nb; bb += 8) {   // 8 independent loads in flight per thread
+            float gv[8];
 #pragma unroll
-            for (int q = 0; q < LT / 4; ++q) {
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[bb * LT + q * 4]);
+            for (int u = 0; u < 8; ++u) gv[u] = (bb + u < nb) ? tofloat(dd0[(size_t)(bc + bb + u) * F + fp]) : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += zz[e] * g;
+            for (int u = 0; u < 8; ++u) {
+                sb += gv[u];
+#pragma unroll
+                for (int q = 0; q < LT / 4; ++q) {
+                    const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[(bb + u) * LT + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q * 4 + e] += zz[e] * gv[u];
+                }
             }
         }
     }

@@ -134,14 +134,15 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
     const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
     const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
     const size_t per = (size_t)9 * CA * CB;
-    int nsplit = std::max(1, 768 / chan_tiles);
+    int nsplit = std::max(1, 1024 / chan_tiles);
     const size_t cap = (size_t)(24u << 20) / 4;  // bound slab traffic to 24 MiB per layer
-    nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / (per * WK)));
+    nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / per));
     nsplit = std::min(nsplit, n_tiles);
     const int tps = (n_tiles + nsplit - 1) / nsplit;
     nsplit = (n_tiles + tps - 1) / tps;
+    (void)WK;
     *nsplit_out = nsplit; *tps_out = tps; *WA_out = WA; *WB_out = WB;
-    return per * nsplit * WK;
+    return per * nsplit;
 }
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
@@ -237,6 +238,7 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     const int n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int NT = std::min(4, a.Cout / 32);
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (2 * th + 1) * (2 * tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
     dim3 grid(n_tiles, a.Cout / (32 * NT));
@@ -257,6 +259,7 @@ static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     const int n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    a.m_pp = fastdiv_magic((th + 1) * (tw + 1)); a.m_pw = fastdiv_magic(tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int NT = std::min(2, a.Cout / 32);
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * (th + 1) * (tw + 1) * PATCH_PITCH + 4 * NT * 32 * 2 * 4;
     dim3 grid(n_tiles, a.Cout / (32 * NT));
@@ -272,7 +275,7 @@ static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 }
 
 static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int CA, int CB, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB);
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB);
     LAUNCH_CHECK("reduce_slab_kernel");
     return 0;
 }
@@ -287,9 +290,11 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
     a.slab = c->slab; a.use_tr16 = c->use_tr16;
+    a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int WK = 4 / (WA * WB);
-    const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
-                       (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16);
+    const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 +
+                       std::max<size_t>((size_t)WG_KP * (32 * WA * sizeof(T) + 16) + (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16),
+                                        (size_t)(4 - WA * WB) * 16 * 64 * 4);
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
     ProfScope ps(c, "wgrad(+slab reduce)",
@@ -299,7 +304,8 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     if (WA == 2 && WB == 2) WG_CASE(2, 2) else if (WA == 2 && WB == 1) WG_CASE(2, 1) else WG_CASE(1, 1)
 #undef WG_CASE
     LAUNCH_CHECK("wgrad_kernel");
-    return launch_reduce(c->slab, nsplit * WK, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
+    (void)WK;
+    return launch_reduce(c->slab, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
 }
 
 template <typename T>
@@ -466,7 +472,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         LatentFwdArgs la;
         la.slab = c->slab; la.nslab = nsplit; la.npad = c->npad_fc; la.bmu = params + c->poff[17]; la.bvar = params + c->poff[19];
         la.eps = c->eps; la.mu = mu; la.lv = lv; la.z = z; la.accum = c->accum; la.B = B; la.L = L;
-        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, la);
+        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, la);
         LAUNCH_CHECK("latent_fwd_kernel");
     }
     // decoder_input
@@ -582,9 +588,9 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         LatentBwdArgs lb;
         lb.slab = c->slab; lb.nslab = nsplit; lb.npad = c->npad_di; lb.mu = c->mu; lb.lv = c->lv; lb.eps = c->eps; lb.gscale = gscale;
         lb.gmu = g_mu; lb.glv = g_lv; lb.gz = g_z; lb.dlat = c->dlat; lb.B = B; lb.L = L; lb.kld_weight = kld_weight; lb.add_kl = add_kl;
-        hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, lb);
+        hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, lb);
         LAUNCH_CHECK("latent_bwd_kernel");
-        hipLaunchKernelGGL(colsum_kernel, dim3((2 * L + 63) / 64), dim3(64), 0, st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L);
+        hipLaunchKernelGGL(colsum_kernel, dim3(2 * L), dim3(64), 0, st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L);
         LAUNCH_CHECK("colsum_kernel");
     }
     // fc_mu / fc_var backward
