@@ -59,6 +59,54 @@ __device__ __forceinline__ Vec16<T> load_transform16(const T* s0, const T* s1, b
     return o;
 }
 
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> transform16(const Vec16<T>& v0, const Vec16<T>& v1, bool two, const float* cf, int C,
+                                                int cb, float slope) {
+    Vec16<T> o;
+    if (two) {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e)
+            o.set(e, leaky(v0.get(e) * cf[cb + e] + v1.get(e) * cf[C + cb + e] + cf[2 * C + cb + e], slope));
+    } else {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) o.set(e, leaky(v0.get(e) * cf[cb + e] + cf[2 * C + cb + e], slope));
+    }
+    return o;
+}
+
+// Stage `nitems` 16-byte chunks global -> (transform) -> LDS.  NB chunks per thread are loaded
+// before any is consumed, so NB (x2 for gradient operands) HBM requests per lane are in flight
+// instead of one dependent load at a time.  map(it, ok, g, loff, cb): item -> validity, global
+// element offset, LDS byte offset, first channel.  Invalid items store zeros (conv padding).
+template <typename T, int NB, typename F>
+__device__ __forceinline__ void stage_items(int tid, int nitems, const T* s0, const T* s1, bool two, const float* cf,
+                                            int C, float slope, char* lds, F&& map) {
+    for (int base = tid; base < nitems; base += 256 * NB) {
+        Vec16<T> v0[NB], v1[NB];
+        int loff[NB], cb[NB];
+        bool ok[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int it = base + u * 256;
+            size_t g = 0;
+            loff[u] = -1; cb[u] = 0; ok[u] = false;
+            if (it < nitems) map(it, ok[u], g, loff[u], cb[u]);
+            if (!ok[u]) g = 0;
+            v0[u] = *reinterpret_cast<const Vec16<T>*>(s0 + g);
+            if (two) v1[u] = *reinterpret_cast<const Vec16<T>*>(s1 + g); else v1[u] = v0[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (loff[u] >= 0) {
+                Vec16<T> o = transform16<T>(v0[u], v1[u], two, cf, C, cb[u], slope);
+                if (!ok[u]) o = zero_vec16<T>();
+                *reinterpret_cast<Vec16<T>*>(lds + loff[u]) = o;
+            }
+        }
+    }
+}
+
 // Common epilogue for one accumulator value.
 template <typename T>
 __device__ __forceinline__ void epi_store(const ConvArgs<T>& a, size_t idx, int n, float accv, float bv, float sc,
@@ -81,7 +129,7 @@ __device__ __forceinline__ void epi_store(const ConvArgs<T>& a, size_t idx, int 
 
 // ---------------------------------------------------------------------------
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
+__global__ __launch_bounds__(256, 2) void down_kernel(ConvArgs<T> a) {
     const bool TWO_SRC = a.two_src != 0; const int EPI = a.epi;
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,17 +158,15 @@ __global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();
-        for (int it = tid; it < npix * 4; it += 256) {
+        stage_items<T, 4>(tid, npix * 4, a.src0, a.src1, TWO_SRC, cf, Cin, a.slope, patch,
+                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int pix = it >> 2, q = it & 3;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = 2 * oy0 - 1 + py, ix = 2 * ox0 - 1 + px;
-            Vec16<T> v = zero_vec16<T>();
-            if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-                const size_t g = (((size_t)b * Hin + iy) * Win + ix) * Cin + c0 + q * E16;
-                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, g, cf, Cin, c0 + q * E16, a.slope);
-            }
-            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
-        }
+            loff = pix * PATCH_PITCH + q * 16; cb = c0 + q * E16;
+            ok = b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            g = (((size_t)b * Hin + iy) * Win + ix) * Cin + cb;
+        });
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -177,7 +223,7 @@ __global__ __launch_bounds__(256) void down_kernel(ConvArgs<T> a) {
 
 // ---------------------------------------------------------------------------
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
+__global__ __launch_bounds__(256, 2) void up_kernel(ConvArgs<T> a) {
     const bool TWO_SRC = a.two_src != 0; const int EPI = a.epi;
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,17 +260,15 @@ __global__ __launch_bounds__(256) void up_kernel(ConvArgs<T> a) {
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();
-        for (int it = tid; it < npix * 4; it += 256) {
+        stage_items<T, 4>(tid, npix * 4, a.src0, a.src1, TWO_SRC, cf, Cin, a.slope, patch,
+                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int pix = it >> 2, q = it & 3;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = iy0 + py, ix = ix0 + px;
-            Vec16<T> v = zero_vec16<T>();
-            if (b < a.B && iy < Hs && ix < Ws) {
-                const size_t g = (((size_t)b * Hs + iy) * Ws + ix) * Cin + c0 + q * E16;
-                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, g, cf, Cin, c0 + q * E16, a.slope);
-            }
-            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
-        }
+            loff = pix * PATCH_PITCH + q * 16; cb = c0 + q * E16;
+            ok = b < a.B && iy < Hs && ix < Ws;
+            g = (((size_t)b * Hs + iy) * Ws + ix) * Cin + cb;
+        });
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -314,19 +358,20 @@ __device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1
 }
 
 template <typename T, int WA, int WB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
-    const bool S_TWO = a.s_two != 0, G_TWO = a.g_two != 0;
-    constexpr int WK = 4 / (WA * WB), E16 = 16 / sizeof(T);
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
+    // 4 waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
+    constexpr int TS = 4 / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
     constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
     constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
+    const bool S_TWO = a.s_two != 0, G_TWO = a.g_two != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP;
     const int Hs = a.Hs, Ws = a.Ws, Hg = 2 * a.Hs, Wg = 2 * a.Ws, CA = a.CA, CB = a.CB;
     const int a0 = blockIdx.y * 32 * WA, bc0 = blockIdx.z * 32 * WB;
-    const int wa = wave % WA, wb = (wave / WA) % WB, wk = wave / (WA * WB);
+    const int wa = wave % WA, wb = (wave / WA) % WB, ts = wave / (WA * WB);
 
     float* cfs = reinterpret_cast<float*>(smem);             // [3][32*WA]
     float* cfg = cfs + 3 * 32 * WA;                          // [3][32*WB]
@@ -336,9 +381,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
     for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
 
-    f32x16 acc[9];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -351,33 +396,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
         const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
         __syncthreads();
-        for (int it = tid; it < WG_KP * SCH; it += 256) {
+        // coefficient rows are stored tile-local (stride 32*WA / 32*WB), channel index = chunk*E16
+        stage_items<T, 2>(tid, WG_KP * SCH, a.s0, a.s1, S_TWO, cfs, 32 * WA, a.sslope, stile,
+                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int k = it / SCH, qq = it - k * SCH;
             const int b = b0 + (k >> (a.lth + a.ltw)), y = y0 + ((k >> a.ltw) & (th - 1)), x = x0 + (k & (tw - 1));
-            Vec16<T> v = zero_vec16<T>();
-            if (b < a.B) {
-                const size_t g = (((size_t)b * Hs + y) * Ws + x) * CA + a0 + qq * E16;
-                v = load_transform16<T>(a.s0, a.s1, S_TWO, g, cfs, 32 * WA, qq * E16, a.sslope);
-                // note: coefficient rows are stored tile-local (stride 32*WA), channel index qq*E16
-            }
-            *reinterpret_cast<Vec16<T>*>(stile + k * SPITCH + qq * 16) = v;
-        }
-        for (int it = tid; it < npix * GCH; it += 256) {
+            loff = k * SPITCH + qq * 16; cb = qq * E16; ok = b < a.B;
+            g = (((size_t)b * Hs + y) * Ws + x) * CA + a0 + qq * E16;
+        });
+        stage_items<T, 4>(tid, npix * GCH, a.g0, a.g1, G_TWO, cfg, 32 * WB, a.gslope, gtile,
+                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int pix = it / GCH, qq = it - pix * GCH;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             const int b = b0 + img, iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
-            Vec16<T> v = zero_vec16<T>();
-            if (b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg) {
-                const size_t g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
-                v = load_transform16<T>(a.g0, a.g1, G_TWO, g, cfg, 32 * WB, qq * E16, a.gslope);
-            }
-            *reinterpret_cast<Vec16<T>*>(gtile + pix * GPITCH + qq * 16) = v;
-        }
+            loff = pix * GPITCH + qq * 16; cb = qq * E16;
+            ok = b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg;
+            g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
+        });
         __syncthreads();
 
-        for (int ks = wk; ks < WG_KP / 16; ks += WK) {
+#pragma unroll 1
+        for (int ks = 0; ks < WG_KP / 16; ++ks) {
             Frag<T> af;
-            int growbase[8];  // patch pixel index (tap 0,0) of the 8 k rows this lane touches
+            int growbase[8];  // patch pixel index (tap 0,0) of the k rows this lane addresses
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -402,56 +443,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = (t / 3) * PW + (t % 3);
-                Frag<T> bf;
-                if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        bf.v[j] = *reinterpret_cast<const float*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 4);
-                } else {
-                    if (a.use_tr16) {
-                        const int col = (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
-                        bf = frag_tr16(gtile + (growbase[0] + toff) * GPITCH + col, gtile + (growbase[1] + toff) * GPITCH + col);
-                    } else {
+            for (int ti = 0; ti < NTW; ++ti) {
+                const int t = ts + ti * TS;
+                if (t < 9) {   // wave-uniform
+                    const int ky = (t * 11) >> 5, kx = t - 3 * ky;
+                    const int toff = ky * PW + kx;
+                    Frag<T> bf;
+                    if constexpr (sizeof(T) == 4) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            bf.v[j] = *reinterpret_cast<const bf16*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 2);
+                            bf.v[j] = *reinterpret_cast<const float*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 4);
+                    } else {
+                        if (a.use_tr16) {
+                            const int col = (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                            bf = frag_tr16(gtile + (growbase[0] + toff) * GPITCH + col, gtile + (growbase[1] + toff) * GPITCH + col);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                bf.v[j] = *reinterpret_cast<const bf16*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 2);
+                        }
                     }
+                    mma(acc[ti], af, bf);
                 }
-                mma(acc[t], af, bf);
             }
         }
     }
 
-    // combine the WK wave-level K splits through LDS (staging area is free now), one tap at a time
-    if constexpr (WK > 1) {
-        float* xch = reinterpret_cast<float*>(stile);   // [(WK-1)*WA*WB waves][16][64]
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            __syncthreads();
-            if (wk > 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) xch[(((wk - 1) * WA * WB + wb * WA + wa) * 16 + i) * 64 + lane] = acc[t][i];
-            }
-            __syncthreads();
-            if (wk == 0) {
-#pragma unroll
-                for (int w = 0; w < WK - 1; ++w)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] += xch[((w * WA * WB + wb * WA + wa) * 16 + i) * 64 + lane];
-            }
-        }
-    }
     // partial slab: rows = low-res-side channel (a), lanes = high-res-side channel (b)
-    if (wk == 0) {
-        const size_t slab_id = blockIdx.x;
+    const size_t slab_id = blockIdx.x;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+    for (int ti = 0; ti < NTW; ++ti) {
+        const int t = ts + ti * TS;
+        if (t < 9) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ca = a0 + wa * 32 + acc_row(i, lane), cb = bc0 + wb * 32 + r;
-                a.slab[((slab_id * 9 + t) * CA + ca) * CB + cb] = acc[t][i];
+                a.slab[((slab_id * 9 + t) * CA + ca) * CB + cb] = acc[ti][i];
             }
         }
     }
