@@ -123,6 +123,31 @@ def test_tr16_and_scalar_wgrad_agree():
     assert rel_l2(grads[1].cpu().numpy(), grads[0].cpu().numpy()) < 1e-5
 
 
+def test_mfma_and_valu_output_conv_backward_agree():
+    """bf16 mode: the MFMA output-conv backward against the f32-VALU formulation of the same math."""
+    from torch_vae_amd import _lib
+    H, L, B, gen = 64, 16, 5, True
+    p = perturbed_params(L, H, 8, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 12)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 12, 5).reshape(B, L)).float().cuda()
+    grads = []
+    for use in (0, 1):
+        model = make_model(H, L, gen, "bf16", p)
+        model._context(B)
+        assert _lib.lib().vae_set_option(model._ctx.handle, b"use_mfma_convout", use) == 0
+        model.fused_forward_backward(x, eps=eps)
+        grads.append(flat_grad_dict(model))
+    for n in grads[0]:
+        if n in PRE_BN_BIAS:
+            continue
+        a, b = grads[1][n].astype(np.float64), grads[0][n].astype(np.float64)
+        cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > 0.995, (n, cos)
+    assert rel_l2(grads[1]["final_layer.3.weight"], grads[0]["final_layer.3.weight"]) < 1e-2
+    assert rel_l2(grads[1]["final_layer.3.bias"], grads[0]["final_layer.3.bias"]) < 1e-4
+    assert rel_l2(grads[1]["final_layer.1.weight"], grads[0]["final_layer.1.weight"]) < 1e-2
+
+
 @pytest.mark.parametrize("name", ["R_b32_k1", "G_h64_l16_b4"])
 def test_f32_training_trajectory(name):
     """Loss curve, parameters and BN running statistics over several fused steps (forward, ELBO,

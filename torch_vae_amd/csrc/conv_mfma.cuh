@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void up_kernel(ConvArgs<T> a) {
 
     for (int c0 = 0; c0 < Cin; c0 += CK) {
         __syncthreads();
-        stage_items<T, 4>(tid, npix * 4, a.src0, a.src1, TWO_SRC, cf, Cin, a.slope, patch,
+        stage_items<T, 3>(tid, npix * 4, a.src0, a.src1, TWO_SRC, cf, Cin, a.slope, patch,
                           [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int pix = it >> 2, q = it & 3;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
         const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
         __syncthreads();
         // coefficient rows are stored tile-local (stride 32*WA / 32*WB), channel index = chunk*E16
-        stage_items<T, 2>(tid, WG_KP * SCH, a.s0, a.s1, S_TWO, cfs, 32 * WA, a.sslope, stile,
+        stage_items<T, WA>(tid, WG_KP * SCH, a.s0, a.s1, S_TWO, cfs, 32 * WA, a.sslope, stile,
                           [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
             const int k = it / SCH, qq = it - k * SCH;
             const int b = b0 + (k >> (a.lth + a.ltw)), y = y0 + ((k >> a.ltw) & (th - 1)), x = x0 + (k & (tw - 1));
@@ -514,6 +514,152 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
             out[j] = s;
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------
+// Output-conv backward on MFMA (bf16 mode).  Same math as convout_bwd_kernel (edge_kernels.cuh):
+//   dA[p][c] = sum_t dl[p-off(t)] w[t][c]        -> one 32x32x16 MFMA per 32 pixels (K = 9 taps, padded)
+//   dW[c][t] += sum_p a[p][c] dl[p-off(t)]       -> K = pixels, A operand read k-major (tr16) from the y tile
+//   dz = dA * leaky'(z), per-channel sum dz, sum dz*xhat, sum dl
+// Persistent workgroups walk 8x32-pixel tiles; the next tile's y is prefetched into registers while the
+// current one is in the matrix pipe; dz goes out through LDS as whole 64-byte pixels.
+struct ConvOutBwdMfmaArgs {
+    const bf16* yf; const float* ocoef; const float* wt; const float* dlogit; const float* gscale;
+    bf16* dz; float* slab; double* stat; double* dbias;
+    int B, H, W, n_tiles; float slope;
+};
+
+__global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfmaArgs a) {
+    constexpr int TH = 8, TW = 32, PITCH = 80, DW = TW + 2, DH = TH + 2;
+    __shared__ __attribute__((aligned(16))) char ytile[TH * TW * PITCH];
+    __shared__ float dl_s[DH * DW + 6];
+    __shared__ float red[4][32 * 9 + 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const float sc = a.ocoef[LC_SC * 32 + r], sh = a.ocoef[LC_SH * 32 + r];
+    const float is = a.ocoef[LC_INVSTD * 32 + r], xm = a.ocoef[LC_XM * 32 + r];
+
+    // weights as the B operand of dA: B[k = tap][col = channel r]
+    Frag<bf16> wfrag;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int t = 8 * h + j; wfrag.v[j] = (bf16)(t < 9 ? a.wt[t * 32 + r] : 0.f); }
+
+    f32x16 accw;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accw[i] = 0.f;
+    float s1 = 0.f, s2 = 0.f, sdl = 0.f;
+
+    auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
+    };
+    // each thread owns 4 of the tile's 1024 16-byte chunks: chunk id = tid + 256*u -> pixel id>>2, quarter id&3
+    bf16x8 pre[4];
+    auto prefetch = [&](int tile) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * u, pix = id >> 2, qq = id & 3;
+            const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
+            pre[u] = *reinterpret_cast<const bf16x8*>(a.yf + g);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) prefetch(tile);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * u;
+            *reinterpret_cast<bf16x8*>(ytile + (id >> 2) * PITCH + (id & 3) * 16) = pre[u];
+        }
+        for (int i = tid; i < DH * DW; i += 256) {
+            const int rr = i / DW, cc = i - rr * DW, gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.dlogit[((size_t)b * a.H + gy) * a.W + gx] * gs;
+            dl_s[i] = v;
+            if (rr >= 1 && rr <= TH && cc >= 1 && cc <= TW) sdl += v;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.n_tiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs below
+
+        // ---- dA: 2 blocks of 32 pixels per wave (tile rows 2*wave, 2*wave+1)
+        f32x16 acca[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acca[mb][i] = 0.f;
+            const int ly = 2 * wave + mb, lx = r;
+            Frag<bf16> af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 8 * h + j, tt = t < 9 ? t : 0;
+                const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
+                af.v[j] = (bf16)(t < 9 ? v : 0.f);
+            }
+            mma(acca[mb], af, wfrag);
+        }
+        // ---- dW: K = the wave's 64 pixels, A = a^T (k-major via tr16 + BN/LeakyReLU), B = dl taps
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k0 = wave * 64 + ks * 16 + 8 * (g4 >> 1) + q, k1 = k0 + 4;
+            const int col = (16 * (g4 & 1) + 4 * p) * 2;
+            Frag<bf16> yfrag = frag_tr16(ytile + k0 * PITCH + col, ytile + k1 * PITCH + col);
+            Frag<bf16> afr, bfr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) afr.v[j] = (bf16)leaky((float)yfrag.v[j] * sc + sh, a.slope);
+            const int tt = r < 9 ? r : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pix = wave * 64 + ks * 16 + 8 * h + j, ly = pix >> 5, lx = pix & 31;
+                const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
+                bfr.v[j] = (bf16)(r < 9 ? v : 0.f);
+            }
+            mma(accw, afr, bfr);
+        }
+        // ---- epilogue: dz = dA * leaky'(z) written in place over this wave's own y rows
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pix = (2 * wave + mb) * 32 + acc_row(i, lane);
+                bf16* cell = reinterpret_cast<bf16*>(ytile + pix * PITCH) + r;
+                const float yv = (float)(*cell), z = yv * sc + sh;
+                const float dzv = (float)(bf16)(z > 0.f ? acca[mb][i] : acca[mb][i] * a.slope);
+                *cell = (bf16)dzv;
+                s1 += dzv; s2 += dzv * (yv * is + xm);
+            }
+        }
+        // the wave re-reads only its own 64 pixels (in-order LDS within a wave): 4 KiB = 4 chunks per lane
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(ytile + pix * PITCH + qq * 16);
+            const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
+            *reinterpret_cast<bf16x8*>(a.dz + g) = v;
+        }
+    }
+
+    // ---- workgroup reductions: dW (rows = channel, lanes 0..8 = tap), statistics, sum of dlogit
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    sdl = wave_sum(sdl);
+    __syncthreads();
+    if (r < 9) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][r * 32 + acc_row(i, lane)] = accw[i];
+    }
+    if (h == 0) { red[wave][288 + r] = s1; red[wave][320 + r] = s2; }
+    if (lane == 0) red[wave][352] = sdl;
+    __syncthreads();
+    for (int j = tid; j < 288; j += 256) a.slab[(size_t)blockIdx.x * 288 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (tid < 64) unsafeAtomicAdd(&a.stat[tid], (double)(red[0][288 + tid] + red[1][288 + tid] + red[2][288 + tid] + red[3][288 + tid]));
+    if (tid == 64) unsafeAtomicAdd(a.dbias, (double)(red[0][352] + red[1][352] + red[2][352] + red[3][352]));
 }
 
 // ---------------------------------------------------------------------------

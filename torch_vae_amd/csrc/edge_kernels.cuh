@@ -479,6 +479,17 @@ __global__ void colsum_kernel(const float* __restrict__ m, int rows, int cols, f
 // f' (NHWC flatten: pix*256 + c) -> reference flatten index c*s2 + pix (models.py:133)
 __device__ __forceinline__ int fref_of(int fp, int s2) { return (fp & 255) * s2 + (fp >> 8); }
 
+// Block `blk` of 256 flatten positions, enumerated so that consecutive threads own consecutive
+// REFERENCE indices (c*s2 + pix): stores of [.,F_ref]-major gradients coalesce; the strided reads
+// of the small NHWC bottleneck tensor are absorbed by L2.
+__device__ __forceinline__ void fmap_ref_major(int blk, int tid, int s2, int& fp, int& fr) {
+    const int P = s2 < 16 ? s2 : 16, CW = 256 / P;          // pixels x channels per block (32-B read runs, 64-B write runs)
+    const int pb = s2 / P;                                   // pixel blocks per channel group
+    const int cblk = blk / pb, pblk = blk - cblk * pb;
+    const int pix = pblk * P + (tid % P), c = cblk * CW + tid / P;
+    fp = pix * 256 + c; fr = c * s2 + pix;
+}
+
 // pre_latents in the reference's NCHW-flatten order (types_helpers.py:20), on request only.
 template <typename T>
 __global__ void pre_latents_kernel(const T* __restrict__ y, const float* __restrict__ coef, float slope,
@@ -549,7 +560,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
     constexpr int JT = 32, BC = 64;
     __shared__ __attribute__((aligned(16))) float dl_s[BC * JT];
-    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, j0 = blockIdx.y * JT, L2 = 2 * a.L;
+    const int tid = threadIdx.x, j0 = blockIdx.y * JT, L2 = 2 * a.L;
+    int fp, fr;
+    fmap_ref_major(blockIdx.x, tid, a.s2, fp, fr);
     const int c = fp & 255;
     const float sc = a.coef[c], sh = a.coef[512 + c];
     float acc[JT];
@@ -578,7 +591,6 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
                 }
         }
     }
-    const int fr = fref_of(fp, a.s2);
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int jj = j0 + j;
@@ -620,7 +632,9 @@ __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ 
                                                           float* __restrict__ dwd, float* __restrict__ dbd, int B, int F, int L, int s2) {
     constexpr int LT = 32, BC = 64;
     __shared__ __attribute__((aligned(16))) float z_s[BC * LT];
-    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, l0 = blockIdx.y * LT, fr = fref_of(fp, s2);
+    const int tid = threadIdx.x, l0 = blockIdx.y * LT;
+    int fp, fr;
+    fmap_ref_major(blockIdx.x, tid, s2, fp, fr);
     float acc[LT], sb = 0.f;
 #pragma unroll
     for (int l = 0; l < LT; ++l) acc[l] = 0.f;

@@ -92,7 +92,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -147,7 +147,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -219,6 +219,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
 extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!c) return vae_set_error("vae_set_option", "null ctx");
     if (!strcmp(name, "use_tr16")) { c->use_tr16 = value; return 0; }
+    if (!strcmp(name, "use_mfma_convout")) { c->use_mfma_convout = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -541,9 +542,18 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
         a.dz = c->lay[7].dz; a.slab = c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
         const long P = (long)B * H * H;
-        const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        int grid = (int)std::min<long>((P + 63) / 64, 1024);
         ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
-        hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
+        if (sizeof(T) == 2 && c->use_mfma_convout) {
+            ConvOutBwdMfmaArgs m;
+            m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.ocoef = a.ocoef; m.wt = a.wt; m.dlogit = a.dlogit; m.gscale = a.gscale;
+            m.dz = reinterpret_cast<bf16*>(c->lay[7].dz); m.slab = c->slab; m.stat = a.stat; m.dbias = a.dbias;
+            m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32); m.slope = kSlope;
+            grid = std::min(m.n_tiles, 1024);
+            hipLaunchKernelGGL(convout_bwd_mfma_kernel, dim3(grid), dim3(256), 0, st, m);
+        } else {
+            hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
+        }
         LAUNCH_CHECK("convout_bwd_kernel");
         if (launch_reduce(c->slab, grid, 288, grads + c->poff[38], 1, 32, st)) return -1;
         hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st, c->accum + 2, grads + c->poff[39], 1, 1.f);
