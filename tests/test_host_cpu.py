@@ -1,0 +1,162 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/vae_step.h declares,
+host-side layout logic, optimiser/scheduler construction, and the data-parallel reduction path
+(world_size 2 over gloo).  No kernel is launched here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from torch_vae_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vae_step.h")).read()
+    declared = set(re.findall(r"\b(vae_[a-z0-9_]+)\s*\(", hdr)) - {"vae_ctx"}
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == declared
+    assert L.vae_abi_version() == 1
+
+
+def test_param_layout_matches_reference_census():
+    from torch_vae_amd import _lib
+    from oracle import vae_oracle as vo
+    offs, sizes, total = _lib.param_layout(32, 16, False)
+    assert sum(sizes) == 836353                      # SURVEY.md 8a parameter census
+    shapes = vo.param_shapes(16, 32)
+    assert list(shapes) == list(_lib.PARAM_NAMES)
+    assert [int(np.prod(s)) for s in shapes.values()] == sizes
+    assert all(o % 64 == 0 for o in offs) and total >= offs[-1] + sizes[-1]
+    _, sizes_g, _ = _lib.param_layout(128, 16, True)
+    assert sum(sizes_g) == 1588993                   # SURVEY.md 8d, G(128,16)
+    with pytest.raises(ValueError):
+        _lib.param_layout(64, 16, False)             # the reference-exact model only exists at 32x32
+    with pytest.raises(ValueError):
+        _lib.param_layout(48, 16, True)
+
+
+def test_model_mirror_surface_and_state_dict_keys():
+    from torch_vae_amd.models import VanillaVAE
+    hd = [32, 64, 128, 256]
+    m = VanillaVAE(1, 16, 32, hidden_dims=hd, kld_weight=2.0)
+    assert hd == [256, 128, 64, 32]                  # models.py:60 mutates the caller's list
+    assert m.name == "VanillaVAE" and m.latent_dim == 16 and m.kld_weight == 2.0
+    sd = m.state_dict()
+    from oracle import vae_oracle as vo
+    want = set(vo.param_shapes(16, 32)) | set(vo.init_bn_state())
+    assert set(sd) == want
+    assert sum(p.numel() for p in m.encoder.parameters()) == 388800
+    assert sum(p.numel() for p in m.decoder.parameters()) == 387744
+    # reference init rules (models.py:227-236): xavier conv weights + zero bias in encoder/final conv
+    assert float(m.encoder[0][0].bias.abs().max()) == 0.0
+    assert float(m.final_layer[3].bias.abs().max()) == 0.0
+    assert float(m.decoder[0][0].bias.abs().max()) > 0.0   # ConvTranspose2d keeps torch's default init
+
+
+def test_optimizer_groups_and_onecycle_like_reference():
+    from argparse import Namespace
+    from torch_vae_amd.models import VanillaVAE
+    from torch_vae_amd.train import build_optimizer
+    from oracle import vae_oracle as vo
+    m = VanillaVAE(1, 16, 32)
+    cfg = Namespace(batch_size_per_gpu=32, world_size=2, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW",
+                    scheduler="OneCycle", epochs=2, freeze_encoder=False)
+    opt, sched = build_optimizer(cfg, m, steps_per_epoch=50)
+    assert cfg.batch_size == 64 and abs(cfg.lr - 0.01 * 64 / 128) < 1e-12       # train.py:165-166,201
+    assert [g["name"] for g in opt.param_groups] == ["encoder", "decoder"]      # train.py:210-225
+    n_opt = sum(p.numel() for g in opt.param_groups for p in g["params"])
+    assert n_opt == 776544
+    oc = vo.OneCycle(cfg.lr, 100)
+    lr0, b0 = oc.value(0)
+    assert abs(opt.param_groups[0]["lr"] - lr0) < 1e-12 and abs(opt.param_groups[0]["betas"][0] - b0) < 1e-12
+
+
+def test_cpu_forward_fails_loudly():
+    from torch_vae_amd.models import VanillaVAE
+    m = VanillaVAE(1, 16, 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 1, 32, 32))
+
+
+def test_roofline_accounting_matches_survey():
+    from torch_vae_amd.models import algorithmic_bytes_per_step, count_flops_per_sample
+    assert abs(count_flops_per_sample(32, 16, False) - 59.1e6) < 0.1e6
+    assert abs(count_flops_per_sample(128, 16, True) - 946.1e6) < 0.2e6
+    assert abs(algorithmic_bytes_per_step(32, 16, 256, 2, False) - 196e6) < 1e6
+    assert abs(algorithmic_bytes_per_step(128, 16, 256, 2, True) - 2.72e9) < 0.01e9
+
+
+_DP_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import vae_oracle as vo
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+H, L, B = 32, 16, 4
+# R replicas: per-replica BatchNorm, averaged gradients, identical AdamW update (SURVEY.md 8e)
+p = vo.init_params(L, H, seed=21, dtype=np.float64)
+tr = vo.make_trainer(L, H, B, 10, seed=21, world_size=world)
+x = vo.synth_pianoroll(B, H, 500 + rank).astype(np.float64)
+eps = vo.counter_normal(B * L, 500 + rank, 5).reshape(B, L)
+
+def allreduce_mean(g):
+    out = {}
+    for k in sorted(g):
+        if k.startswith("__") or k.endswith(".dz"):
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(g[k]))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out[k] = (t / world).numpy()
+    return out
+
+lo, c, g = tr.step(x, eps, grads_override=allreduce_mean)
+# every rank must hold identical parameters after the step
+flat = torch.from_numpy(np.concatenate([tr.p[k].reshape(-1) for k in sorted(tr.p)]))
+ref = flat.clone(); dist.broadcast(ref, 0)
+assert torch.equal(flat, ref), "replicas diverged"
+# and they must equal a single-process simulation of both replicas
+if rank == 0:
+    sims = []
+    for r in range(world):
+        t2 = vo.make_trainer(L, H, B, 10, seed=21, world_size=world)
+        xr = vo.synth_pianoroll(B, H, 500 + r).astype(np.float64); er = vo.counter_normal(B * L, 500 + r, 5).reshape(B, L)
+        cc = vo.forward(t2.p, xr, er, t2.bn_state, train=True); sims.append(vo.backward(t2.p, cc))
+    mean = {k: sum(s[k] for s in sims) / world for k in sims[0] if not k.startswith("__") and not k.endswith(".dz")}
+    t3 = vo.make_trainer(L, H, B, 10, seed=21, world_size=world)
+    t3.step(x, eps, grads_override=lambda _g: mean)
+    for k in t3.p:
+        np.testing.assert_allclose(tr.p[k], t3.p[k], rtol=1e-12, atol=1e-15)
+    assert abs(tr.sched_enc.max_lr - 0.01 * B * world / 128) < 1e-15   # train.py:201 lr scaling by world size
+    print("DP_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_gradient_average_world2_gloo(tmp_path):
+    """The N>1 path: sum-all-reduce of gradients / world, per-replica BN, identical update on every
+    rank (what torch_vae_amd.train.allreduce_gradients + FusedAdamW.grad_scale do with RCCL)."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DP_OK" in r.stdout
+
+
+def test_allreduce_helper_ranges_cover_optimised_groups():
+    from torch_vae_amd.models import VanillaVAE
+    m = VanillaVAE(1, 16, 32)
+    (eo, en), (do, dn) = m.group_range("encoder"), m.group_range("decoder")
+    assert eo == 0 and en >= 388800 and dn >= 387744 and do > eo + en
+    with pytest.raises(ValueError):
+        m.group_range("nonexistent")
