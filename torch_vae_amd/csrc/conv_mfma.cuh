@@ -357,14 +357,18 @@ __device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1
     return f;
 }
 
-template <typename T, int WA, int WB>
+// PRE = true: the next K tile's operand chunks are loaded into registers while the current tile is in
+// the matrix pipe (persistent loop over this workgroup's K tiles).  CONVT selects which side carries
+// the two-source gradient operand (ConvTranspose2d: high-res side; Conv2d: low-res side).
+template <typename T, int WA, int WB, bool CONVT, bool PRE>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
     // 4 waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
     constexpr int TS = 4 / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
     constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
     constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
-    const bool S_TWO = a.s_two != 0, G_TWO = a.g_two != 0;
+    constexpr bool S_TWO = !CONVT, G_TWO = CONVT;
+    constexpr int MAXG = 5 * WB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
@@ -392,28 +396,93 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
 
     const int t_begin = blockIdx.x * a.tiles_per_split;
     const int t_end = min(a.n_tiles, t_begin + a.tiles_per_split);
+
+    auto s_map = [&](int b0, int y0, int x0, int it, bool& ok, size_t& g, int& loff, int& cb) {
+        const int k = it / SCH, qq = it - k * SCH;
+        const int b = b0 + (k >> (a.lth + a.ltw)), y = y0 + ((k >> a.ltw) & (th - 1)), x = x0 + (k & (tw - 1));
+        loff = k * SPITCH + qq * 16; cb = qq * E16; ok = b < a.B;
+        g = (((size_t)b * Hs + y) * Ws + x) * CA + a0 + qq * E16;
+    };
+    auto g_map = [&](int b0, int y0, int x0, int it, bool& ok, size_t& g, int& loff, int& cb) {
+        const int pix = it / GCH, qq = it - pix * GCH;
+        const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
+        const int b = b0 + img, iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+        loff = pix * GPITCH + qq * 16; cb = qq * E16;
+        ok = b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg;
+        g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
+    };
+    auto tile_origin = [&](int tile, int& b0, int& y0, int& x0) {
+        const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
+        b0 = bt << a.lTB; y0 = ty << a.lth; x0 = tx << a.ltw;
+    };
+    // prefetch registers; meta = LDS offset (19 bits) | pad flag (bit 19) | first channel (bits 20+), -1 = none
+    Vec16<T> ps0[PRE ? WA : 1], ps1[(PRE && S_TWO) ? WA : 1], pg0[PRE ? MAXG : 1], pg1[(PRE && G_TWO) ? MAXG : 1];
+    int smeta[PRE ? WA : 1], gmeta[PRE ? MAXG : 1];
+    auto issue_tile = [&](int tile) {
+        int b0, y0, x0; tile_origin(tile, b0, y0, x0);
+#pragma unroll
+        for (int u = 0; u < (PRE ? WA : 0); ++u) {
+            bool ok; size_t g; int loff, cb;
+            s_map(b0, y0, x0, tid + u * 256, ok, g, loff, cb);
+            smeta[u] = loff | (ok ? 0 : 0x80000) | (cb << 20);
+            if (!ok) g = 0;
+            ps0[u] = *reinterpret_cast<const Vec16<T>*>(a.s0 + g);
+            if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(a.s1 + g);
+        }
+#pragma unroll
+        for (int u = 0; u < (PRE ? MAXG : 0); ++u) {
+            const int it = tid + u * 256;
+            gmeta[u] = -1;
+            size_t g = 0;
+            if (it < npix * GCH) {
+                bool ok; int loff, cb;
+                g_map(b0, y0, x0, it, ok, g, loff, cb);
+                gmeta[u] = loff | (ok ? 0 : 0x80000) | (cb << 20);
+                if (!ok) g = 0;
+            }
+            pg0[u] = *reinterpret_cast<const Vec16<T>*>(a.g0 + g);
+            if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(a.g1 + g);
+        }
+    };
+    if constexpr (PRE) { if (t_begin < t_end) issue_tile(t_begin); }
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
-        __syncthreads();
-        // coefficient rows are stored tile-local (stride 32*WA / 32*WB), channel index = chunk*E16
-        stage_items<T, WA>(tid, WG_KP * SCH, a.s0, a.s1, S_TWO, cfs, 32 * WA, a.sslope, stile,
-                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
-            const int k = it / SCH, qq = it - k * SCH;
-            const int b = b0 + (k >> (a.lth + a.ltw)), y = y0 + ((k >> a.ltw) & (th - 1)), x = x0 + (k & (tw - 1));
-            loff = k * SPITCH + qq * 16; cb = qq * E16; ok = b < a.B;
-            g = (((size_t)b * Hs + y) * Ws + x) * CA + a0 + qq * E16;
-        });
-        stage_items<T, 4>(tid, npix * GCH, a.g0, a.g1, G_TWO, cfg, 32 * WB, a.gslope, gtile,
-                          [&](int it, bool& ok, size_t& g, int& loff, int& cb) {
-            const int pix = it / GCH, qq = it - pix * GCH;
-            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-            const int b = b0 + img, iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
-            loff = pix * GPITCH + qq * 16; cb = qq * E16;
-            ok = b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg;
-            g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
-        });
-        __syncthreads();
+        if constexpr (!PRE) {
+            __syncthreads();
+            // coefficient rows are stored tile-local (stride 32*WA / 32*WB), channel index = chunk*E16
+            stage_items<T, WA>(tid, WG_KP * SCH, a.s0, a.s1, S_TWO, cfs, 32 * WA, a.sslope, stile,
+                              [&](int it, bool& ok, size_t& g, int& loff, int& cb) { s_map(b0, y0, x0, it, ok, g, loff, cb); });
+            stage_items<T, 4>(tid, npix * GCH, a.g0, a.g1, G_TWO, cfg, 32 * WB, a.gslope, gtile,
+                              [&](int it, bool& ok, size_t& g, int& loff, int& cb) { g_map(b0, y0, x0, it, ok, g, loff, cb); });
+            __syncthreads();
+        } else {
+            __syncthreads();                       // previous tile consumed
+#pragma unroll
+            for (int u = 0; u < WA; ++u) {
+                Vec16<T> o = transform16<T>(ps0[u], ps1[S_TWO ? u : 0], S_TWO, cfs, 32 * WA, smeta[u] >> 20, a.sslope);
+                if (smeta[u] & 0x80000) o = zero_vec16<T>();
+                *reinterpret_cast<Vec16<T>*>(stile + (smeta[u] & 0x7ffff)) = o;
+            }
+#pragma unroll
+            for (int u = 0; u < MAXG; ++u) {
+                if (gmeta[u] >= 0) {
+                    Vec16<T> o = transform16<T>(pg0[u], pg1[G_TWO ? u : 0], G_TWO, cfg, 32 * WB, gmeta[u] >> 20, a.gslope);
+                    if (gmeta[u] & 0x80000) o = zero_vec16<T>();
+                    *reinterpret_cast<Vec16<T>*>(gtile + (gmeta[u] & 0x7ffff)) = o;
+                }
+            }
+            // patches with more than MAXG*256 chunks (many small images per tile): synchronous remainder
+            for (int it = tid + MAXG * 256; it < npix * GCH; it += 256) {
+                bool ok; size_t g; int loff, cb;
+                g_map(b0, y0, x0, it, ok, g, loff, cb);
+                Vec16<T> v = zero_vec16<T>();
+                if (ok) v = load_transform16<T>(a.g0, a.g1, G_TWO, g, cfg, 32 * WB, cb, a.gslope);
+                *reinterpret_cast<Vec16<T>*>(gtile + loff) = v;
+            }
+            __syncthreads();                       // tile published
+            if (tile + 1 < t_end) issue_tile(tile + 1);
+        }
 
 #pragma unroll 1
         for (int ks = 0; ks < WG_KP / 16; ++ks) {

@@ -17,6 +17,7 @@ static int vae_set_error(const char* what, const char* why) {
 
 #include "common.cuh"
 #include "conv_mfma.cuh"
+#include "conv_pipe.cuh"
 #include "edge_kernels.cuh"
 
 #define LAUNCH_CHECK(name)                                                        \
@@ -92,7 +93,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -135,7 +136,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
     const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
     const size_t per = (size_t)9 * CA * CB;
     int nsplit = std::max(1, 1024 / chan_tiles);
-    const size_t cap = (size_t)(24u << 20) / 4;  // bound slab traffic to 24 MiB per layer
+    const size_t cap = (size_t)(48u << 20) / 4;  // bound slab traffic to 48 MiB per layer
     nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / per));
     nsplit = std::min(nsplit, n_tiles);
     const int tps = (n_tiles + nsplit - 1) / nsplit;
@@ -147,7 +148,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -220,6 +221,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!c) return vae_set_error("vae_set_option", "null ctx");
     if (!strcmp(name, "use_tr16")) { c->use_tr16 = value; return 0; }
     if (!strcmp(name, "use_mfma_convout")) { c->use_mfma_convout = value; return 0; }
+    if (!strcmp(name, "use_pipelined")) { c->use_pipelined = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -233,8 +235,11 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+template <typename T> static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st);
+
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if (c->use_pipelined) return launch_conv_pipe<T>(c, a, true, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -256,6 +261,7 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 
 template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if (c->use_pipelined) return launch_conv_pipe<T>(c, a, false, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -272,6 +278,40 @@ static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     if (NT == 1) UP_CASE(1) else UP_CASE(2)
 #undef UP_CASE
     LAUNCH_CHECK("up_kernel");
+    return 0;
+}
+
+// persistent, prefetched variants (conv_pipe.cuh)
+template <typename T>
+static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st) {
+    Tiling t = make_tiling(a.Hs, a.Ws, 128);
+    a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
+    const int n_mt = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    const int PHW = is_down ? (2 * th + 1) * (2 * tw + 1) : (th + 1) * (tw + 1);
+    a.m_pp = fastdiv_magic(PHW); a.m_pw = fastdiv_magic(is_down ? 2 * tw + 1 : tw + 1);
+    a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
+    // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
+    int NT = std::min(2, a.Cout / 32);
+    if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
+    const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
+    const size_t opitch = 32 * NT * sizeof(T) + 16;
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : 3, (160 * 1024) / lds));
+    int grid = std::min(n_pairs, 256 * per_cu);
+    grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
+    const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
+    const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
+    ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
+                 sizeof(T) * (px_in * a.Cin * (a.two_src ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
+                 2.0 * 9 * a.Cin * a.Cout * px_lo, st);
+#define PIPE_CASE(K, N, W) { if (set_lds(K<T, N, W>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
+#define PIPE_SRC(K, N) { if (a.two_src) PIPE_CASE(K, N, true) else PIPE_CASE(K, N, false) }
+    if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else PIPE_SRC(down2_kernel, 2) }
+    else { if (NT == 1) PIPE_SRC(up2_kernel, 1) else PIPE_SRC(up2_kernel, 2) }
+#undef PIPE_SRC
+#undef PIPE_CASE
+    LAUNCH_CHECK("conv_pipe_kernel");
     return 0;
 }
 
@@ -300,8 +340,15 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     ProfScope ps(c, "wgrad(+slab reduce)",
                  sizeof(T) * (px_s * a.CA * (a.s_two ? 2 : 1) + 4 * px_s * a.CB * (a.g_two ? 2 : 1)) + 4.0 * 9 * a.CA * a.CB,
                  2.0 * 9 * a.CA * a.CB * px_s, st);
-#define WG_CASE(A_, B_) { if (set_lds(wgrad_kernel<T, A_, B_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_>), grid, dim3(256), lds, st, a); }
-    if (WA == 2 && WB == 2) WG_CASE(2, 2) else if (WA == 2 && WB == 1) WG_CASE(2, 1) else WG_CASE(1, 1)
+    // s_two/g_two identify the layer kind: Conv2d (gradient on the low-res side) or ConvTranspose2d
+    if (a.s_two == a.g_two) return vae_set_error("wgrad", "exactly one operand must be the gradient");
+    const bool convt = a.g_two != 0, pre = c->use_pipelined && sizeof(T) == 2 && !(WA == 2 && WB == 2);
+#define WG_CASE(A_, B_, C_, P_) { if (set_lds(wgrad_kernel<T, A_, B_, C_, P_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_, C_, P_>), grid, dim3(256), lds, st, a); }
+#define WG_KIND(A_, B_, P_) { if (convt) WG_CASE(A_, B_, true, P_) else WG_CASE(A_, B_, false, P_) }
+    if (WA == 2 && WB == 2) WG_KIND(2, 2, false)
+    else if (WA == 2 && WB == 1) { if (pre) WG_KIND(2, 1, true) else WG_KIND(2, 1, false) }
+    else { if (pre) WG_KIND(1, 1, true) else WG_KIND(1, 1, false) }
+#undef WG_KIND
 #undef WG_CASE
     LAUNCH_CHECK("wgrad_kernel");
     (void)WK;
