@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
 template <typename T> struct FcWgradArgs {
     const float* dlat; const T* y; const float* coef; float slope;
     float* dwmu; float* dwvar; int B, F, L, s2;
+    int bsplit;             // batch rows per grid.z slice; slice z writes slab z of dwmu / dwvar ([nz][L][F] each)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
@@ -568,14 +569,15 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
     float acc[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[j] = 0.f;
-    for (int bc = 0; bc < a.B; bc += BC) {
+    const int bz0 = blockIdx.z * a.bsplit, bz1 = min(a.B, bz0 + a.bsplit);
+    for (int bc = bz0; bc < bz1; bc += BC) {
         __syncthreads();
         for (int i = tid; i < BC * JT; i += 256) {
             const int bb = i / JT, j = i % JT;
-            dl_s[i] = (bc + bb < a.B && j0 + j < L2) ? a.dlat[(size_t)(bc + bb) * L2 + j0 + j] : 0.f;
+            dl_s[i] = (bc + bb < bz1 && j0 + j < L2) ? a.dlat[(size_t)(bc + bb) * L2 + j0 + j] : 0.f;
         }
         __syncthreads();
-        const int nb = min(BC, a.B - bc);
+        const int nb = min(BC, bz1 - bc);
         for (int bb = 0; bb < nb; bb += 8) {   // 8 independent loads in flight per thread
             float av[8];
 #pragma unroll
@@ -594,8 +596,9 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgradArgs<T> a) {
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int jj = j0 + j;
-        if (jj < a.L) a.dwmu[(size_t)jj * a.F + fr] = acc[j];
-        else if (jj < L2) a.dwvar[(size_t)(jj - a.L) * a.F + fr] = acc[j];
+        const size_t zoff = (size_t)blockIdx.z * a.L * a.F;
+        if (jj < a.L) a.dwmu[zoff + (size_t)jj * a.F + fr] = acc[j];
+        else if (jj < L2) a.dwvar[zoff + (size_t)(jj - a.L) * a.F + fr] = acc[j];
     }
 }
 
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict_
 // decoder_input weight/bias gradient: dWd[f][l] = sum_b dd0[b][f'] z[b][l]; dbd[f] = sum_b dd0[b][f']
 template <typename T>
 __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ dd0, const float* __restrict__ z,
-                                                          float* __restrict__ dwd, float* __restrict__ dbd, int B, int F, int L, int s2) {
+                                                          float* __restrict__ dwd, float* __restrict__ dbd, int B, int F, int L, int s2,
+                                                          int bsplit) {   // grid.z slice z -> slab z of dwd ([nz][F][L]) and dbd ([nz][F])
     constexpr int LT = 32, BC = 64;
     __shared__ __attribute__((aligned(16))) float z_s[BC * LT];
     const int tid = threadIdx.x, l0 = blockIdx.y * LT;
@@ -638,14 +642,15 @@ __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ 
     float acc[LT], sb = 0.f;
 #pragma unroll
     for (int l = 0; l < LT; ++l) acc[l] = 0.f;
-    for (int bc = 0; bc < B; bc += BC) {
+    const int bz0 = blockIdx.z * bsplit, bz1 = min(B, bz0 + bsplit);
+    for (int bc = bz0; bc < bz1; bc += BC) {
         __syncthreads();
         for (int i = tid; i < BC * LT; i += 256) {
             const int bb = i / LT, l = i % LT;
-            z_s[i] = (bc + bb < B && l0 + l < L) ? z[(size_t)(bc + bb) * L + l0 + l] : 0.f;
+            z_s[i] = (bc + bb < bz1 && l0 + l < L) ? z[(size_t)(bc + bb) * L + l0 + l] : 0.f;
         }
         __syncthreads();
-        const int nb = min(BC, B - bc);
+        const int nb = min(BC, bz1 - bc);
         for (int bb = 0; bb < nb; bb += 8) {   // 8 independent loads in flight per thread
             float gv[8];
 #pragma unroll
@@ -664,8 +669,8 @@ __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int l = 0; l < LT; ++l)
-        if (l0 + l < L) dwd[(size_t)fr * L + l0 + l] = acc[l];
-    if (blockIdx.y == 0) dbd[fr] = sb;
+        if (l0 + l < L) dwd[(size_t)blockIdx.z * F * L + (size_t)fr * L + l0 + l] = acc[l];
+    if (blockIdx.y == 0) dbd[(size_t)blockIdx.z * F + fr] = sb;
 }
 
 // ---------------------------------------------------------------------------

@@ -206,6 +206,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
         const size_t ksteps = c->F / 16;
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_fc);
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_di);
+        slab = std::max(slab, (size_t)8 * (2 * (size_t)L * c->F + c->F));   // fc / decoder_input weight-gradient batch slices
         c->slab_floats = slab;
         c->slab = dalloc<float>(c, slab);
         ok = c->slab != nullptr;
@@ -631,11 +632,17 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     }
     // decoder_input backward, reparameterisation + KL backward
     {
-        dim3 grid((unsigned)(c->F / 256), (L + 31) / 32);
-        ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
-        hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(c->dd0), c->z,
-                           grads + c->poff[20], grads + c->poff[21], B, (int)c->F, L, c->s2);
-        LAUNCH_CHECK("decin_wgrad_kernel");
+        {
+            // batch split over grid.z (8 slices) -> slabs -> one reduce per tensor
+            const int nz = std::max(1, std::min(8, B / 8)), bsplit = (B + nz - 1) / nz;
+            float* sw = c->slab; float* sb = c->slab + (size_t)nz * c->F * L;
+            dim3 grid((unsigned)(c->F / 256), (L + 31) / 32, nz);
+            ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
+            hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(c->dd0), c->z, sw, sb, B, (int)c->F, L, c->s2, bsplit);
+            LAUNCH_CHECK("decin_wgrad_kernel");
+            if (launch_reduce(sw, nz, (size_t)c->F * L, grads + c->poff[20], 0, 0, st)) return -1;
+            if (launch_reduce(sb, nz, (size_t)c->F, grads + c->poff[21], 0, 0, st)) return -1;
+        }
         DenseArgs<T> a; memset(&a, 0, sizeof(a));
         a.A = reinterpret_cast<const T*>(c->dd0); a.coef = nullptr; a.slope = 1.f; a.C = 256;
         a.Bp = reinterpret_cast<const T*>(c->dipack); a.M = B; a.K = (int)c->F; a.Npad = c->npad_di;
@@ -654,9 +661,17 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         FcWgradArgs<T> w;
         w.dlat = c->dlat; w.y = reinterpret_cast<const T*>(c->lay[3].y); w.coef = c->lay[3].block; w.slope = kSlope;
         w.dwmu = grads + c->poff[16]; w.dwvar = grads + c->poff[18]; w.B = B; w.F = (int)c->F; w.L = L; w.s2 = c->s2;
-        ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, st);
-        hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32), dim3(256), 0, st, w);
-        LAUNCH_CHECK("fc_wgrad_kernel");
+        {
+            const int nz = std::max(1, std::min(8, B / 8));
+            w.bsplit = (B + nz - 1) / nz;
+            float* smu = c->slab; float* svar = c->slab + (size_t)nz * L * c->F;
+            w.dwmu = smu; w.dwvar = svar;
+            ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, st);
+            hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, st, w);
+            LAUNCH_CHECK("fc_wgrad_kernel");
+            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, st)) return -1;
+            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, st)) return -1;
+        }
         FcDgradArgs<T> d;
         d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
         d.ocoef = c->lay[3].block; d.slope = kSlope; d.gpre = g_pre; d.dz = reinterpret_cast<T*>(c->lay[3].dz); d.stat = c->lay[3].stat_b;
