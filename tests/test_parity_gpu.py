@@ -143,8 +143,8 @@ def test_mfma_and_valu_output_conv_backward_agree():
         a, b = grads[1][n].astype(np.float64), grads[0][n].astype(np.float64)
         cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
         assert cos > 0.995, (n, cos)
-    assert rel_l2(grads[1]["final_layer.3.weight"], grads[0]["final_layer.3.weight"]) < 1e-2
-    assert rel_l2(grads[1]["final_layer.3.bias"], grads[0]["final_layer.3.bias"]) < 1e-4
+    assert rel_l2(grads[1]["final_layer.3.weight"], grads[0]["final_layer.3.weight"]) < 2e-2
+    assert rel_l2(grads[1]["final_layer.3.bias"], grads[0]["final_layer.3.bias"]) < 2e-3
     assert rel_l2(grads[1]["final_layer.1.weight"], grads[0]["final_layer.1.weight"]) < 1e-2
 
 

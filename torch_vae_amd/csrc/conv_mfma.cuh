@@ -587,6 +587,113 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
 
 
 // ---------------------------------------------------------------------------
+// Output conv forward + sigmoid + BCE + dlogit on MFMA (bf16 mode); same math as convout_fwd_kernel.
+//   part[p][t] = sum_c a[p][c] w[t][c]   : M = patch pixels (tile + 1-pixel halo), K = 32 channels, N = 9 taps
+//   logit[q]   = bias + sum_t part[q + off(t)][t]
+// Persistent workgroups over 8x32-pixel tiles; next tile's (8+2)x(32+2) patch of y is prefetched.
+struct ConvOutFwdMfmaArgs {
+    const bf16* yf; const float* coef; const float* wt; const float* bias; const float* target;
+    float* xhat; float* dlogit; double* accum;
+    int B, H, W, n_tiles; float inv_n, slope;
+};
+
+__global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfmaArgs a) {
+    constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NP = PH * PW, NPAD = 384, PITCH = 80, NCHK = NP * 4, MAXI = 6;
+    __shared__ __attribute__((aligned(16))) char atile[NPAD * PITCH];
+    __shared__ float part[NPAD * 9];
+    __shared__ float cf[64];
+    __shared__ float wred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    if (tid < 32) { cf[tid] = a.coef[tid]; cf[32 + tid] = a.coef[64 + tid]; }
+    // rows NP..NPAD of the patch image stay zero
+    for (int i = tid; i < (NPAD - NP) * PITCH / 16; i += 256) *reinterpret_cast<f32x4*>(atile + NP * PITCH + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B operand: B[k = channel][col = tap r]
+    Frag<bf16> wf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[ks].v[j] = (bf16)(r < 9 ? a.wt[r * 32 + ks * 16 + 8 * h + j] : 0.f);
+    const float bo = a.bias[0];
+    float bsum = 0.f;
+
+    auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
+    };
+    bf16x8 pre[MAXI]; int ok[MAXI]; float pretg;
+    auto prefetch = [&](int tile) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+        pretg = a.target[((size_t)b * a.H + y0 + (tid >> 5)) * a.W + x0 + (tid & 31)];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int id = tid + 256 * u, pix = id >> 2, qq = id & 3;
+            const int py = pix / PW, px = pix - py * PW, gy = y0 - 1 + py, gx = x0 - 1 + px;
+            ok[u] = id < NCHK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const size_t g = ok[u] ? (((size_t)b * a.H + gy) * a.W + gx) * 32 + qq * 8 : 0;
+            pre[u] = *reinterpret_cast<const bf16x8*>(a.yf + g);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) prefetch(tile);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCHK) {
+                const int qq = id & 3;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(ok[u] ? leaky((float)pre[u][e] * cf[qq * 8 + e] + cf[32 + qq * 8 + e], a.slope) : 0.f);
+                *reinterpret_cast<bf16x8*>(atile + (id >> 2) * PITCH + qq * 16) = o;
+            }
+        }
+        __syncthreads();
+        const float tg = pretg;
+        if (tile + (int)gridDim.x < a.n_tiles) prefetch(tile + gridDim.x);
+        // 12 row blocks of 32 patch pixels, 3 per wave
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) {
+            const int row0 = (wave * 3 + mb) * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<bf16> af = load_frag(reinterpret_cast<const bf16*>(atile + (row0 + r) * PITCH + ks * 32) + h * 8);
+                mma(acc, af, wf[ks]);
+            }
+            if (r < 9) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) part[(row0 + acc_row(i, lane)) * 9 + r] = acc[i];
+            }
+        }
+        __syncthreads();
+        // 256 output pixels, one per thread
+        {
+            const int oy = tid >> 5, ox = tid & 31;
+            float logit = bo;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) logit += part[((oy + t / 3) * PW + ox + t % 3) * 9 + t];
+            const size_t gi = ((size_t)b * a.H + y0 + oy) * a.W + x0 + ox;
+            const float xh = 1.f / (1.f + expf(-logit));
+            const float l1 = fmaxf(logf(xh), -100.f), l0 = fmaxf(logf(1.f - xh), -100.f);
+            bsum += -(tg * l1 + (1.f - tg) * l0);
+            const float om = xh * (1.f - xh);
+            a.xhat[gi] = xh;
+            a.dlogit[gi] = (xh - tg) / fmaxf(om, 1e-12f) * om * a.inv_n;
+        }
+    }
+    bsum = wave_sum(bsum);
+    if (lane == 0) wred[wave] = bsum;
+    __syncthreads();
+    if (tid == 0) unsafeAtomicAdd(&a.accum[0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+}
+
+// ---------------------------------------------------------------------------
 // Output-conv backward on MFMA (bf16 mode).  Same math as convout_bwd_kernel (edge_kernels.cuh):
 //   dA[p][c] = sum_t dl[p-off(t)] w[t][c]        -> one 32x32x16 MFMA per 32 pixels (K = 9 taps, padded)
 //   dW[c][t] += sum_p a[p][c] dl[p-off(t)]       -> K = pixels, A operand read k-major (tr16) from the y tile
@@ -627,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
     };
     // each thread owns 4 of the tile's 1024 16-byte chunks: chunk id = tid + 256*u -> pixel id>>2, quarter id&3
     bf16x8 pre[4];
+    float predl[2];     // and up to 2 of the (TH+2)x(TW+2) dlogit values
     auto prefetch = [&](int tile) {
         int b, y0, x0; tile_origin(tile, b, y0, x0);
 #pragma unroll
@@ -634,6 +742,13 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
             const int id = tid + 256 * u, pix = id >> 2, qq = id & 3;
             const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
             pre[u] = *reinterpret_cast<const bf16x8*>(a.yf + g);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, rr = i / DW, cc = i - rr * DW, gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+            const bool in = i < DH * DW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const float v = a.dlogit[in ? ((size_t)b * a.H + gy) * a.W + gx : 0];
+            predl[u] = in ? v * gs : 0.f;
         }
     };
 
@@ -647,12 +762,13 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
             const int id = tid + 256 * u;
             *reinterpret_cast<bf16x8*>(ytile + (id >> 2) * PITCH + (id & 3) * 16) = pre[u];
         }
-        for (int i = tid; i < DH * DW; i += 256) {
-            const int rr = i / DW, cc = i - rr * DW, gy = y0 - 1 + rr, gx = x0 - 1 + cc;
-            float v = 0.f;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.dlogit[((size_t)b * a.H + gy) * a.W + gx] * gs;
-            dl_s[i] = v;
-            if (rr >= 1 && rr <= TH && cc >= 1 && cc <= TW) sdl += v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, rr = i / DW, cc = i - rr * DW;
+            if (i < DH * DW) {
+                dl_s[i] = predl[u];
+                if (rr >= 1 && rr <= TH && cc >= 1 && cc <= TW) sdl += predl[u];
+            }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < a.n_tiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs below

@@ -326,6 +326,21 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
         }
     };
 
+    // one N tile per workgroup for its whole life: epilogue coefficients live in registers
+    float ebv[NT], esc[NT], esh[NT], eis[NT], exm[NT];
+    {
+        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0w + nt * 32 + r;
+            ebv[nt] = (EPI == EPI_FWD && a.bias) ? a.bias[n] : 0.f;
+            esc[nt] = esh[nt] = eis[nt] = exm[nt] = 0.f;
+            if (EPI == EPI_BWD) {
+                esc[nt] = a.ocoef[LC_SC * Cout + n]; esh[nt] = a.ocoef[LC_SH * Cout + n];
+                eis[nt] = a.ocoef[LC_INVSTD * Cout + n]; exm[nt] = a.ocoef[LC_XM * Cout + n];
+            }
+        }
+    }
     int pi = blockIdx.x, chunk = 0;
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
@@ -379,13 +394,7 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = cur.n0 + nt * 32 + r;
-                    float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f;
-                    if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
-                    if (EPI == EPI_BWD) {
-                        sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
-                        is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
-                    }
+                    const float bv = ebv[nt], sc = esc[nt], sh = esh[nt], is = eis[nt], xm = exm[nt];
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
 #pragma unroll

@@ -506,45 +506,53 @@ template <typename T> struct FcDgradArgs {
     const T* y; const float* ocoef; float slope;
     const float* gpre;                          // optional external grad on pre_latents [B,F] (reference order)
     T* dz; double* stat; int B, F, L2, s2;
+    int bt_per_wg;   // batch rows per workgroup (multiple of 16)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
     constexpr int BT = 16;
     extern __shared__ __attribute__((aligned(16))) float dl_s[];  // [L2][BT]
-    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid, b0 = blockIdx.y * BT;
-    for (int i = tid; i < a.L2 * BT; i += 256) {
-        const int j = i / BT, bb = i % BT;
-        dl_s[i] = (b0 + bb < a.B) ? a.dlat[(size_t)(b0 + bb) * a.L2 + j] : 0.f;
-    }
-    __syncthreads();
-    float acc[BT];
-#pragma unroll
-    for (int bb = 0; bb < BT; ++bb) acc[bb] = 0.f;
-    const T* wrow = a.wp + ((size_t)(fp >> 3) * a.npad) * 8 + (fp & 7);
-    for (int j = 0; j < a.L2; ++j) {
-        const float w = tofloat(wrow[(size_t)j * 8]);
-#pragma unroll
-        for (int q = 0; q < BT / 4; ++q) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[j * BT + q * 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * w;
-        }
-    }
+    const int tid = threadIdx.x, fp = blockIdx.x * 256 + tid;
     const int c = fp & 255;
     const float sc = a.ocoef[LC_SC * 256 + c], sh = a.ocoef[LC_SH * 256 + c];
     const float is = a.ocoef[LC_INVSTD * 256 + c], xm = a.ocoef[LC_XM * 256 + c];
+    const T* wrow = a.wp + ((size_t)(fp >> 3) * a.npad) * 8 + (fp & 7);
     float s1 = 0.f, s2 = 0.f;
+    const int bend = min(a.B, (int)(blockIdx.y + 1) * a.bt_per_wg);
+    for (int b0 = blockIdx.y * a.bt_per_wg; b0 < bend; b0 += BT) {
+        __syncthreads();
+        for (int i = tid; i < a.L2 * BT; i += 256) {
+            const int j = i / BT, bb = i % BT;
+            dl_s[i] = (b0 + bb < a.B) ? a.dlat[(size_t)(b0 + bb) * a.L2 + j] : 0.f;
+        }
+        __syncthreads();
+        float yv[BT], acc[BT];
 #pragma unroll
-    for (int bb = 0; bb < BT; ++bb) {
-        const int b = b0 + bb;
-        if (b < a.B) {
-            const size_t idx = (size_t)b * a.F + fp;
-            float da = acc[bb];
-            if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(fp, a.s2)];
-            const float yv = tofloat(a.y[idx]), z = yv * sc + sh;
-            const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
-            a.dz[idx] = fromfloat<T>(dzv);
-            s1 += dzv; s2 += dzv * (yv * is + xm);
+        for (int bb = 0; bb < BT; ++bb) {   // y rows in flight while the dot products run
+            acc[bb] = 0.f;
+            yv[bb] = (b0 + bb < a.B) ? tofloat(a.y[(size_t)(b0 + bb) * a.F + fp]) : 0.f;
+        }
+        for (int j = 0; j < a.L2; ++j) {
+            const float w = tofloat(wrow[(size_t)j * 8]);
+#pragma unroll
+            for (int q = 0; q < BT / 4; ++q) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(&dl_s[j * BT + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * w;
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+            const int b = b0 + bb;
+            if (b < a.B) {
+                const size_t idx = (size_t)b * a.F + fp;
+                float da = acc[bb];
+                if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(fp, a.s2)];
+                const float z = yv[bb] * sc + sh;
+                const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
+                a.dz[idx] = fromfloat<T>(dzv);
+                s1 += dzv; s2 += dzv * (yv[bb] * is + xm);
+            }
         }
     }
     unsafeAtomicAdd(&a.stat[c], (double)s1);

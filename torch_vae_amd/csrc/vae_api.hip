@@ -93,7 +93,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout, use_pipelined; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -148,7 +148,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -198,7 +198,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
         ok = c->fcpack && c->dipack && c->d_descs;
     }
     // slab: max over all split-K users
-    size_t slab = 1024 * 288;  // conv1 wgrad / convout bwd: up to 1024 workgroups x 288
+    size_t slab = 2048 * 288;  // conv1 wgrad / convout bwd: up to 2048 workgroups x 288
     if (ok) {
         int a, b2, wa, wb;
         for (int i = 1; i < 4; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H, c->lay[i].W, co[i], ci[i], &a, &b2, &wa, &wb));
@@ -223,6 +223,8 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_tr16")) { c->use_tr16 = value; return 0; }
     if (!strcmp(name, "use_mfma_convout")) { c->use_mfma_convout = value; return 0; }
     if (!strcmp(name, "use_pipelined")) { c->use_pipelined = value; return 0; }
+    if (!strcmp(name, "knob_up_per_cu")) { c->knob_up_per_cu = value; return 0; }
+    if (!strcmp(name, "knob_convout_grid")) { c->knob_convout_grid = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -298,7 +300,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : 3, (160 * 1024) / lds));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
     int grid = std::min(n_pairs, 256 * per_cu);
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
     const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
@@ -489,7 +491,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     // encoder block 0
     {
         const long P = (long)B * (H / 2) * (H / 2);
-        const int grid = (int)std::min<long>((P + 63) / 64, 2048);
+        const int grid = (int)std::min<long>((P + 63) / 64, 512);   // few workgroups: one f64 atomic per channel each
         ProfScope ps(c, "conv1_fwd", 4.0 * B * H * H + (double)sizeof(T) * 32.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
@@ -548,7 +550,15 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
         a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
         ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
-        hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
+        if (sizeof(T) == 2 && c->use_mfma_convout) {
+            ConvOutFwdMfmaArgs m;
+            m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.coef = a.coef; m.wt = a.wt; m.bias = a.bias; m.target = x;
+            m.xhat = xhat; m.dlogit = c->dlogit; m.accum = c->accum; m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
+            m.inv_n = a.inv_n; m.slope = kSlope;
+            hipLaunchKernelGGL(convout_fwd_mfma_kernel, dim3(std::min(m.n_tiles, c->knob_convout_grid)), dim3(256), 0, st, m);
+        } else {
+            hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
+        }
         LAUNCH_CHECK("convout_fwd_kernel");
     }
     return 0;
@@ -597,7 +607,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
             m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.ocoef = a.ocoef; m.wt = a.wt; m.dlogit = a.dlogit; m.gscale = a.gscale;
             m.dz = reinterpret_cast<bf16*>(c->lay[7].dz); m.slab = c->slab; m.stat = a.stat; m.dbias = a.dbias;
             m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32); m.slope = kSlope;
-            grid = std::min(m.n_tiles, 1024);
+            grid = std::min(m.n_tiles, c->knob_convout_grid);
             hipLaunchKernelGGL(convout_bwd_mfma_kernel, dim3(grid), dim3(256), 0, st, m);
         } else {
             hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
@@ -677,7 +687,8 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         d.ocoef = c->lay[3].block; d.slope = kSlope; d.gpre = g_pre; d.dz = reinterpret_cast<T*>(c->lay[3].dz); d.stat = c->lay[3].stat_b;
         d.B = B; d.F = (int)c->F; d.L2 = 2 * L; d.s2 = c->s2;
         ProfScope ps2(c, "fc_dgrad", (double)sizeof(T) * (2.0 * B * c->F + 2.0 * c->F * L), 4.0 * B * c->F * L, st);
-        hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + 15) / 16), dim3(256), 2 * L * 16 * 4, st, d);
+        d.bt_per_wg = std::max(16, ((B + 7) / 8 + 15) / 16 * 16);   // <= 8 workgroups per channel: fewer same-address atomics
+        hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + d.bt_per_wg - 1) / d.bt_per_wg), dim3(256), 2 * L * 16 * 4, st, d);
         LAUNCH_CHECK("fc_dgrad_kernel");
     }
     // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
@@ -699,7 +710,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     {
         if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
-        const int grid = (int)std::min<long>((P + 63) / 64, 1024);
+        const int grid = (int)std::min<long>((P + 63) / 64, 512);
         ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const T*>(c->lay[0].dz),
                            reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, c->slab, B, H, H);
