@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--dump-order", default=None, help="write the per-step launch order (label, kernel symbol) as JSON")
     return ap.parse_args()
 
 
@@ -114,6 +115,11 @@ def main():
             step(args.warmup + args.steps + i)
         buf = ctypes.create_string_buffer(1 << 16)
         _lib.check(L_.vae_profile_report(model._ctx.handle, buf, len(buf)), "vae_profile_report")
+        if args.dump_order:
+            sbuf = ctypes.create_string_buffer(1 << 18)
+            _lib.check(L_.vae_profile_sequence(model._ctx.handle, sbuf, len(sbuf)), "vae_profile_sequence")
+            seq = json.loads(sbuf.value.decode())
+            json.dump(seq[:len(seq) // nprof], open(args.dump_order, "w"))
         _lib.check(L_.vae_profile(model._ctx.handle, 0), "vae_profile")
         kernels = json.loads(buf.value.decode())
         for k in kernels:
@@ -123,8 +129,18 @@ def main():
         kernels.sort(key=lambda k: -k["ms"])
         dom = kernels[0]
         ach = dom["gbs"]
+        # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+        # passes; tools/pmc_traffic.py writes profiles/pmc_traffic.json on the GPU box) - null when not collected
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{dom['name']}|H{H}|L{L}|B{B}|{args.dtype}"
+            if key in tj:
+                traffic = tj[key]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom["name"],
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom["name"],
                     "avg_launch_us": round(1e3 * dom["ms_per_call"], 2),
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
                     "kernel_tflops": round(dom["tflops"], 1)}

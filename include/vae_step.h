@@ -117,6 +117,8 @@ int vae_synth_pianoroll(float* x, int batch, int img_size, uint64_t seed, vae_st
  * calls, total ms, and total ALGORITHMIC bytes / flops (operand tensors once). */
 int vae_profile(vae_ctx* ctx, int enable);
 int vae_profile_report(vae_ctx* ctx, char* buf, int64_t capacity);
+/* JSON array of the labels of all profiled launches, in launch order. */
+int vae_profile_sequence(vae_ctx* ctx, char* buf, int64_t capacity);
 
 /* Debug / test hooks: copy an internal NHWC tensor to f32 NCHW.  which: 0..7 raw conv output
  * of BN layer i, 8..15 its dz, 16 decoder_input output, 17 its gradient. */

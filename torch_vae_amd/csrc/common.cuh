@@ -43,6 +43,17 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero_vec16() {
     return r;
 }
 
+// Streaming (read-once / write-once) accesses: non-temporal, so the activation streams do not evict the
+// weight images that every workgroup re-reads from L2.
+template <typename T> __device__ __forceinline__ Vec16<T> load_stream(const T* p) {
+    Vec16<T> r;
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(r.v)*>(p));
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store_stream(T* p, const Vec16<T>& v) {
+    __builtin_nontemporal_store(v.v, reinterpret_cast<decltype(v.v)*>(p));
+}
+
 // ---- MFMA fragment: 8 k-values per lane, k = 8*(lane>>5) + j ---------------
 // bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight v_mfma_f32_32x32x2_f32, step j
 // contracting k in {j, 8+j}; the k permutation is the same for A and B, so the

@@ -65,9 +65,10 @@ __device__ __forceinline__ Vec16<T> transform16(const Vec16<T>& v0, const Vec16<
                                                 int cb, float slope) {
     Vec16<T> o;
     if (two) {
+        // gradient operand: dL/dy = dz*p0 + y*p1 + p2 (the launchers pass slope = 1, so no LeakyReLU here)
 #pragma unroll
         for (int e = 0; e < Vec16<T>::N; ++e)
-            o.set(e, leaky(v0.get(e) * cf[cb + e] + v1.get(e) * cf[C + cb + e] + cf[2 * C + cb + e], slope));
+            o.set(e, v0.get(e) * cf[cb + e] + v1.get(e) * cf[C + cb + e] + cf[2 * C + cb + e]);
     } else {
 #pragma unroll
         for (int e = 0; e < Vec16<T>::N; ++e) o.set(e, leaky(v0.get(e) * cf[cb + e] + cf[2 * C + cb + e], slope));

@@ -26,7 +26,7 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 
 // ---------------------------------------------------------------------------
 template <typename T, int NT, bool TWO_SRC>
-__global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+__global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 10;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;   // out-tile row bytes / chunks
     constexpr int OPL = OCH / 2;                                                     // out chunks per lane (32 px per wave)
@@ -41,6 +41,14 @@ __global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pair
     char* otile = patch + npix * PATCH_PITCH;                 // [4 waves][32 px][OPITCH]
     float* red = reinterpret_cast<float*>(otile + 128 * OPITCH);
     char* mytile = otile + wave * 32 * OPITCH;
+    // per-item staging table (tile-independent): {relative global element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
+    int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
+    for (int it = tid; it < nitems; it += 256) {
+        const int pix = it >> 2, q = it & 3;
+        const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
+        itab[it] = make_int2(((img * Hin + py) * Win + px) * Cin + q * E16,
+                             ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15));
+    }
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
 
@@ -56,51 +64,52 @@ __global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pair
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
     }
 
-    Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1], prey[OPL];
-    int meta[MAXI];   // LDS byte offset of the item; bit 31 set = padding (store zeros)
+    Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1];
+    decltype(Vec16<T>::v) prey[OPL];   // raw vectors: keeps the prefetch in VGPRs (a struct array was demoted to scratch)
 
-    auto issue = [&](const TileGeo& g, int c0) {
+    // item -> (LDS offset, validity, global offset); recomputed where needed instead of kept in registers:
+    // any spilled dword is reloaded through scratch, whose loads share vmcnt with the prefetch burst.
+    auto item_geo = [&](const TileGeo& g, int c0, int it, int& loff, bool& ok, size_t& gi) __attribute__((always_inline)) {
+        const int2 e = itab[it < nitems ? it : 0];
+        // the halo row/column (py==0 / px==0) falls outside the image only for tiles on the top / left border
+        ok = (it < nitems) & ((g.b0 + (e.y >> 15)) < a.B) & !(((e.y >> 13) & 1) & (g.y0 == 0)) & !(((e.y >> 14) & 1) & (g.x0 == 0));
+        loff = (e.y & 0x1fff) << 4;
+        const long base = (((long)g.b0 * Hin + 2 * g.y0 - 1) * Win + 2 * g.x0 - 1) * Cin + c0;
+        gi = ok ? (size_t)(base + e.x) : 0;
+    };
+    auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int it = tid + u * 256;
-            size_t gi = 0; meta[u] = -1;
-            if (it < nitems) {
-                const int pix = it >> 2, q = it & 3;
-                const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-                const int b = g.b0 + img, iy = 2 * g.y0 - 1 + py, ix = 2 * g.x0 - 1 + px;
-                const bool ok = b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-                meta[u] = (pix * PATCH_PITCH + q * 16) | (ok ? 0 : 0x40000000);
-                if (ok) gi = (((size_t)b * Hin + iy) * Win + ix) * Cin + c0 + q * E16;
-            }
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, tid + u * 256, loff, ok, gi);
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
         }
     };
-    auto write_patch = [&](const TileGeo& g, int c0) {
+    auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            if (meta[u] >= 0) {
+            const int it = tid + u * 256;
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, it, loff, ok, gi);
+            if (it < nitems) {
                 // chunk quarter q = item & 3 (256 % 4 == 0), so the first channel of the chunk is c0 + q*E16
-                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + ((tid + u * 256) & 3) * E16, a.slope);
-                if (meta[u] & 0x40000000) o = zero_vec16<T>();
-                *reinterpret_cast<Vec16<T>*>(patch + (meta[u] & 0x3fffffff)) = o;
+                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + (it & 3) * E16, a.slope);
+                if (!ok) o = zero_vec16<T>();
+                *reinterpret_cast<Vec16<T>*>(patch + loff) = o;
             }
         }
         // patches larger than MAXI*256 chunks (tiny spatial sizes, many images per tile): synchronous tail
         for (int it = tid + MAXI * 256; it < nitems; it += 256) {
-            const int pix = it >> 2, q = it & 3;
-            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-            const int b = g.b0 + img, iy = 2 * g.y0 - 1 + py, ix = 2 * g.x0 - 1 + px;
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, it, loff, ok, gi);
             Vec16<T> v = zero_vec16<T>();
-            if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-                const size_t gi = (((size_t)b * Hin + iy) * Win + ix) * Cin + c0 + q * E16;
-                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + q * E16, a.slope);
-            }
-            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
+            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + (it & 3) * E16, a.slope);
+            *reinterpret_cast<Vec16<T>*>(patch + loff) = v;
         }
     };
     // global element offset of out-tile chunk (wave-local chunk id) or -1
-    auto out_chunk_addr = [&](const TileGeo& g, int id, int& loff) -> long {
+    auto out_chunk_addr = [&](const TileGeo& g, int id, int& loff) __attribute__((always_inline)) -> long {
         const int row = id / OCH, qq = id - row * OCH, RR = wave * 32 + row;
         loff = row * OPITCH + qq * 16;
         const int b = g.b0 + (RR >> (a.lth + a.ltw));
@@ -108,11 +117,11 @@ __global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pair
         const int oy = g.y0 + ((RR >> a.ltw) & (th - 1)), ox = g.x0 + (RR & (tw - 1));
         return ((((long)b * a.Hs + oy) * a.Ws + ox) * Cout + g.n0 + qq * E16);
     };
-    auto issue_y = [&](const TileGeo& g) {
+    auto issue_y = [&](const TileGeo& g) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
             int loff; long gi = out_chunk_addr(g, lane + 64 * u, loff);
-            prey[u] = *reinterpret_cast<const Vec16<T>*>(a.yout + (gi < 0 ? 0 : gi));
+            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
         }
     };
 
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pair
 #pragma unroll
             for (int u = 0; u < OPL; ++u) {
                 int loff; (void)out_chunk_addr(cur, lane + 64 * u, loff);
-                *reinterpret_cast<Vec16<T>*>(mytile + loff) = prey[u];
+                *reinterpret_cast<decltype(Vec16<T>::v)*>(mytile + loff) = prey[u];
             }
         }
         __syncthreads();                                   // (B) patch published
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void down2_kernel(ConvArgs<T> a, int n_pair
 
 // ---------------------------------------------------------------------------
 template <typename T, int NT, bool TWO_SRC>
-__global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+__global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 3;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;
     constexpr int OPL = OCH;                          // 64 output pixels per wave per round (32 base px x 2 x-parities)
@@ -247,6 +256,14 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
     char* otile = patch + npix * PATCH_PITCH;                 // [4 waves][64 px][OPITCH]
     float* red = reinterpret_cast<float*>(otile + 256 * OPITCH);
     char* mytile = otile + wave * 64 * OPITCH;
+    // per-item staging table: {relative global element offset, LDS offset/16 | row<<13 | col<<19 | img<<25}
+    int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
+    for (int it = tid; it < nitems; it += 256) {
+        const int pix = it >> 2, q = it & 3;
+        const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
+        itab[it] = make_int2(((img * Hs + py) * Ws + px) * Cin + q * E16,
+                             ((pix * PATCH_PITCH + q * 16) >> 4) | (py << 13) | (px << 19) | (img << 25));
+    }
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
 
@@ -268,49 +285,48 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
     constexpr int tap_t[NTAP] = {4, 5, 3, 7, 1, 8, 6, 2, 0};
     constexpr int tap_off[NTAP] = {0, 0, 1, 0, 2, 0, 1, 2, 3};  // di*2+dj
 
-    Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1], prey[OPL];
-    int meta[MAXI];
+    Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1];
+    decltype(Vec16<T>::v) prey[OPL];
 
-    auto issue = [&](const TileGeo& g, int c0) {
+    auto item_geo = [&](const TileGeo& g, int c0, int it, int& loff, bool& ok, size_t& gi) __attribute__((always_inline)) {
+        const int2 e = itab[it < nitems ? it : 0];
+        // the bottom/right halo (row th, column tw) leaves the image only on the last tile row / column
+        ok = (it < nitems) & ((g.b0 + (e.y >> 25)) < a.B) & ((g.y0 + ((e.y >> 13) & 63)) < Hs) & ((g.x0 + ((e.y >> 19) & 63)) < Ws);
+        loff = (e.y & 0x1fff) << 4;
+        const long base = (((long)g.b0 * Hs + g.y0) * Ws + g.x0) * Cin + c0;
+        gi = ok ? (size_t)(base + e.x) : 0;
+    };
+    auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int it = tid + u * 256;
-            size_t gi = 0; meta[u] = -1;
-            if (it < nitems) {
-                const int pix = it >> 2, q = it & 3;
-                const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-                const int b = g.b0 + img, iy = g.y0 + py, ix = g.x0 + px;
-                const bool ok = b < a.B && iy < Hs && ix < Ws;
-                meta[u] = (pix * PATCH_PITCH + q * 16) | (ok ? 0 : 0x40000000);
-                if (ok) gi = (((size_t)b * Hs + iy) * Ws + ix) * Cin + c0 + q * E16;
-            }
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, tid + u * 256, loff, ok, gi);
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
         }
     };
-    auto write_patch = [&](const TileGeo& g, int c0) {
+    auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            if (meta[u] >= 0) {
-                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + ((tid + u * 256) & 3) * E16, a.slope);
-                if (meta[u] & 0x40000000) o = zero_vec16<T>();
-                *reinterpret_cast<Vec16<T>*>(patch + (meta[u] & 0x3fffffff)) = o;
+            const int it = tid + u * 256;
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, it, loff, ok, gi);
+            if (it < nitems) {
+                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + (it & 3) * E16, a.slope);
+                if (!ok) o = zero_vec16<T>();
+                *reinterpret_cast<Vec16<T>*>(patch + loff) = o;
             }
         }
         for (int it = tid + MAXI * 256; it < nitems; it += 256) {
-            const int pix = it >> 2, q = it & 3;
-            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-            const int b = g.b0 + img, iy = g.y0 + py, ix = g.x0 + px;
+            int loff; bool ok; size_t gi;
+            item_geo(g, c0, it, loff, ok, gi);
             Vec16<T> v = zero_vec16<T>();
-            if (b < a.B && iy < Hs && ix < Ws) {
-                const size_t gi = (((size_t)b * Hs + iy) * Ws + ix) * Cin + c0 + q * E16;
-                v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + q * E16, a.slope);
-            }
-            *reinterpret_cast<Vec16<T>*>(patch + pix * PATCH_PITCH + q * 16) = v;
+            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + (it & 3) * E16, a.slope);
+            *reinterpret_cast<Vec16<T>*>(patch + loff) = v;
         }
     };
     // round py: wave-local out pixel o = 2*row + px (row = base pixel 0..31) -> LDS row o, global (2i+py, 2j+px)
-    auto out_chunk_addr = [&](const TileGeo& g, int py, int id, int& loff) -> long {
+    auto out_chunk_addr = [&](const TileGeo& g, int py, int id, int& loff) __attribute__((always_inline)) -> long {
         const int o = id / OCH, qq = id - o * OCH, row = o >> 1, px = o & 1, RR = wave * 32 + row;
         loff = o * OPITCH + qq * 16;
         const int b = g.b0 + (RR >> (a.lth + a.ltw));
@@ -318,11 +334,11 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
         const int oy = 2 * (g.y0 + ((RR >> a.ltw) & (th - 1))) + py, ox = 2 * (g.x0 + (RR & (tw - 1))) + px;
         return ((((long)b * 2 * Hs + oy) * 2 * Ws + ox) * Cout + g.n0 + qq * E16);
     };
-    auto issue_y = [&](const TileGeo& g, int py) {
+    auto issue_y = [&](const TileGeo& g, int py) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
             int loff; long gi = out_chunk_addr(g, py, lane + 64 * u, loff);
-            prey[u] = *reinterpret_cast<const Vec16<T>*>(a.yout + (gi < 0 ? 0 : gi));
+            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
         }
     };
 
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void up2_kernel(ConvArgs<T> a, int n_pairs,
 #pragma unroll
                     for (int u = 0; u < OPL; ++u) {
                         int loff; (void)out_chunk_addr(cur, py, lane + 64 * u, loff);
-                        *reinterpret_cast<Vec16<T>*>(mytile + loff) = prey[u];
+                        *reinterpret_cast<decltype(Vec16<T>::v)*>(mytile + loff) = prey[u];
                     }
                     if (py == 0) issue_y(cur, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -93,10 +93,10 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_nt_max; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
-    int prof; struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
+    int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
 };
 
 // RAII: brackets the launches of one logical kernel with events when profiling is on.
@@ -104,7 +104,7 @@ struct ProfScope {
     vae_ctx* c; hipStream_t st; int idx;
     ProfScope(vae_ctx* c_, const char* name, double bytes, double flops, hipStream_t st_) : c(c_), st(st_), idx(-1) {
         if (!c || !c->prof) return;
-        vae_ctx::ProfRec r; r.name = name; r.bytes = bytes; r.flops = flops;
+        vae_ctx::ProfRec r; r.name = std::string(name) + (c->tag ? std::string(" @") + c->tag : std::string()); r.bytes = bytes; r.flops = flops;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
         (void)hipEventRecord(r.e0, st);
         c->prof_recs.push_back(r); idx = (int)c->prof_recs.size() - 1;
@@ -148,8 +148,8 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048;
-    c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 2;
+    c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
     if (maxB < 1) { vae_set_error("vae_create", "max_batch < 1"); delete c; return nullptr; }
@@ -225,6 +225,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_pipelined")) { c->use_pipelined = value; return 0; }
     if (!strcmp(name, "knob_up_per_cu")) { c->knob_up_per_cu = value; return 0; }
     if (!strcmp(name, "knob_convout_grid")) { c->knob_convout_grid = value; return 0; }
+    if (!strcmp(name, "knob_nt_max")) { c->knob_nt_max = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -295,11 +296,13 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     a.m_pp = fastdiv_magic(PHW); a.m_pw = fastdiv_magic(is_down ? 2 * tw + 1 : tw + 1);
     a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
-    int NT = std::min(2, a.Cout / 32);
+    int NT = std::min(c->knob_nt_max, a.Cout / 32);
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
-    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4;
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
+                       (size_t)TB * PHW * 4 * 8;   // + the per-item staging table
+    if (a.two_src && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
     int grid = std::min(n_pairs, 256 * per_cu);
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
@@ -340,7 +343,8 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16);
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
-    ProfScope ps(c, "wgrad(+slab reduce)",
+    {
+    ProfScope ps(c, "wgrad_kernel",
                  sizeof(T) * (px_s * a.CA * (a.s_two ? 2 : 1) + 4 * px_s * a.CB * (a.g_two ? 2 : 1)) + 4.0 * 9 * a.CA * a.CB,
                  2.0 * 9 * a.CA * a.CB * px_s, st);
     // s_two/g_two identify the layer kind: Conv2d (gradient on the low-res side) or ConvTranspose2d
@@ -354,6 +358,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
 #undef WG_KIND
 #undef WG_CASE
     LAUNCH_CHECK("wgrad_kernel");
+    }
     (void)WK;
     return launch_reduce(c->slab, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
 }
@@ -488,7 +493,9 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     c->B = B; c->trained = train; c->x = x; c->xhat = xhat; c->mu = mu; c->lv = lv; c->z = z;
     HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
     if (pack_weights<T>(c, params, st)) return -1;
+    static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // encoder block 0
+    c->tag = kLayerTag[0];
     {
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);   // few workgroups: one f64 atomic per channel each
@@ -499,6 +506,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         if (bn_finalize_fwd(c, 0, params, bn_running, nbt, train, st)) return -1;
     }
     for (int i = 1; i < 4; ++i) {
+        c->tag = kLayerTag[i];
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope;
         a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
@@ -508,6 +516,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
     }
     // fc_mu | fc_var, reparameterize
+    c->tag = "latent";
     {
         DenseArgs<T> a; memset(&a, 0, sizeof(a));
         a.A = reinterpret_cast<const T*>(c->lay[3].y); a.coef = c->lay[3].block; a.slope = kSlope; a.C = 256;
@@ -534,6 +543,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         LAUNCH_CHECK("decin_fwd_kernel");
     }
     for (int i = 4; i < 8; ++i) {
+        c->tag = kLayerTag[i];
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         if (i == 4) { a.src0 = reinterpret_cast<const T*>(c->d0); a.coef = c->ident; a.slope = 1.f; a.Cin = 256; }
         else { a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope; a.Cin = c->lay[i - 1].C; }
@@ -544,6 +554,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
     }
     // output conv + sigmoid + reconstruction loss/gradient
+    c->tag = "final_layer.3";
     {
         ConvOutArgs a;
         a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
@@ -594,7 +605,9 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         LAUNCH_CHECK("dlogit_combine_kernel");
         dl_src = c->dlogit2; dl_scale = nullptr;
     }
+    static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // output conv backward + final_layer BN/LeakyReLU prologue
+    c->tag = "final_layer.3";
     {
         ConvOutBwdArgs a;
         a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
@@ -619,6 +632,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     }
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
     for (int i = 7; i >= 4; --i) {
+        c->tag = kLayerTag[i];
         if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
         const BnLayer& l = c->lay[i];
         const int Cin = i == 4 ? 256 : c->lay[i - 1].C;
@@ -641,6 +655,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (launch_down<T>(c, a, st)) return -1;
     }
     // decoder_input backward, reparameterisation + KL backward
+    c->tag = "latent";
     {
         {
             // batch split over grid.z (8 slices) -> slabs -> one reduce per tensor
@@ -693,6 +708,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     }
     // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
     for (int i = 3; i >= 1; --i) {
+        c->tag = kLayerTag[i];
         if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
         const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
         WgradArgs<T> w; memset(&w, 0, sizeof(w));
@@ -708,6 +724,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (launch_up<T>(c, a, st)) return -1;
     }
     {
+        c->tag = kLayerTag[0];
         if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
@@ -819,6 +836,17 @@ extern "C" int vae_profile_report(vae_ctx* c, char* buf, int64_t cap) {
     }
     out += "]";
     if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_report", "buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
+// JSON array of the profiled launch labels in launch order (for matching rocprofv3 dispatches to labels)
+extern "C" int vae_profile_sequence(vae_ctx* c, char* buf, int64_t cap) {
+    if (!c) return vae_set_error("vae_profile_sequence", "null ctx");
+    std::string out = "[";
+    for (size_t i = 0; i < c->prof_recs.size(); ++i) out += std::string(i ? "," : "") + "\"" + c->prof_recs[i].name + "\"";
+    out += "]";
+    if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_sequence", "buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
