@@ -93,7 +93,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_nt_max; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_nt_max, knob_pipe_max_cout; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -148,7 +148,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 2;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 2; c->knob_pipe_max_cout = 256;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -226,6 +226,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_up_per_cu")) { c->knob_up_per_cu = value; return 0; }
     if (!strcmp(name, "knob_convout_grid")) { c->knob_convout_grid = value; return 0; }
     if (!strcmp(name, "knob_nt_max")) { c->knob_nt_max = value; return 0; }
+    if (!strcmp(name, "knob_pipe_max_cout")) { c->knob_pipe_max_cout = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -243,7 +244,7 @@ template <typename T> static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, boo
 
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
-    if (c->use_pipelined) return launch_conv_pipe<T>(c, a, true, st);
+    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout) return launch_conv_pipe<T>(c, a, true, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -265,7 +266,7 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 
 template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
-    if (c->use_pipelined) return launch_conv_pipe<T>(c, a, false, st);
+    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout) return launch_conv_pipe<T>(c, a, false, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
