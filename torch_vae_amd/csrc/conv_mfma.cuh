@@ -382,6 +382,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
     float* cfg = cfs + 3 * 32 * WA;                          // [3][32*WB]
     char* stile = reinterpret_cast<char*>(cfg + 3 * 32 * WB);  // [64][SPITCH]
     char* gtile = stile + WG_KP * SPITCH;                    // [npix][GPITCH]
+    // tile-independent staging table of the high-res patch: {relative element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
+    int2* gtab = reinterpret_cast<int2*>(gtile + npix * GPITCH);
+    if constexpr (PRE) {
+        for (int it = tid; it < npix * GCH; it += 256) {
+            const int pix = it / GCH, qq = it - pix * GCH;
+            const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
+            gtab[it] = make_int2(((img * Hg + py) * Wg + px) * CB + qq * E16,
+                                 ((pix * GPITCH + qq * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15));
+        }
+    }
 
     for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
     for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
@@ -430,16 +440,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
             ps0[u] = *reinterpret_cast<const Vec16<T>*>(a.s0 + g);
             if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(a.s1 + g);
         }
+        const long gbase = (((long)b0 * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * CB + bc0;
 #pragma unroll
         for (int u = 0; u < (PRE ? MAXG : 0); ++u) {
             const int it = tid + u * 256;
             gmeta[u] = -1;
             size_t g = 0;
             if (it < npix * GCH) {
-                bool ok; int loff, cb;
-                g_map(b0, y0, x0, it, ok, g, loff, cb);
-                gmeta[u] = loff | (ok ? 0 : 0x80000) | (cb << 20);
-                if (!ok) g = 0;
+                const int2 e = gtab[it];
+                const bool ok = ((b0 + (e.y >> 15)) < a.B) & !(((e.y >> 13) & 1) & (y0 == 0)) & !(((e.y >> 14) & 1) & (x0 == 0));
+                const int qq = it % GCH;
+                gmeta[u] = ((e.y & 0x1fff) << 4) | (ok ? 0 : 0x80000) | ((qq * E16) << 20);
+                if (ok) g = (size_t)(gbase + e.x);
             }
             pg0[u] = *reinterpret_cast<const Vec16<T>*>(a.g0 + g);
             if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(a.g1 + g);
