@@ -148,7 +148,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 2; c->knob_pipe_max_cout = 256;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -298,6 +298,8 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
     int NT = std::min(c->knob_nt_max, a.Cout / 32);
+    NT = NT >= 8 ? 8 : (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1));
+    if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
@@ -314,7 +316,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
                  2.0 * 9 * a.Cin * a.Cout * px_lo, st);
 #define PIPE_CASE(K, N, W) { if (set_lds(K<T, N, W>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
 #define PIPE_SRC(K, N) { if (a.two_src) PIPE_CASE(K, N, true) else PIPE_CASE(K, N, false) }
-    if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else PIPE_SRC(down2_kernel, 2) }
+    if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else if (NT == 2) PIPE_SRC(down2_kernel, 2) else if (NT == 4) PIPE_SRC(down2_kernel, 4) else PIPE_SRC(down2_kernel, 8) }
     else { if (NT == 1) PIPE_SRC(up2_kernel, 1) else PIPE_SRC(up2_kernel, 2) }
 #undef PIPE_SRC
 #undef PIPE_CASE
