@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         const int c0 = chunk * CK;
         {
             // weights straight from L1/L2 as the B operand, kept two taps ahead of the matrix pipe
-            constexpr int DEPTH = 2;
+            constexpr int DEPTH = (NT <= 2 ? 4 : 2);   // taps of weight fragments in flight
             Frag<T> bq[DEPTH][KS][NT];
             auto load_b = [&](int t, int slot) {
 #pragma unroll
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                     for (int nt = 0; nt < NT; ++nt) bq[slot][ks][nt] = load_frag(a.wp + (kg * Cout + cur.n0 + nt * 32 + r) * 8);
                 }
             };
-            load_b(0, 0); load_b(1, 1);
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) load_b(d, d);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
 #pragma unroll
@@ -379,14 +380,15 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
 #pragma unroll
             for (int o = 0; o < 4; ++o)
                 af[o] = load_frag(reinterpret_cast<const T*>(patch + (pbase + (o >> 1) * PW + (o & 1)) * PATCH_PITCH + ks * 32) + h * 8);
-            constexpr int DEPTH = 2;
+            constexpr int DEPTH = (NT <= 1 ? 4 : 2);
             Frag<T> bq[DEPTH][NT];
             auto load_b = [&](int k, int slot) {
                 const size_t kg = (size_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq[slot][nt] = load_frag(a.wp + (kg * Cout + cur.n0 + nt * 32 + r) * 8);
             };
-            load_b(0, 0); load_b(1, 1);
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) load_b(d, d);
 #pragma unroll
             for (int k = 0; k < NTAP; ++k) {
 #pragma unroll
