@@ -40,12 +40,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (path test)")
     ap.add_argument("--dump-order", default=None, help="write the per-step launch order (label, kernel symbol) as JSON")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    # Native libraries (RCCL prints a version banner) write to fd 1; keep stdout for the ONE JSON line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -56,7 +61,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the VAE step has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from argparse import Namespace
@@ -187,8 +193,8 @@ def main():
             "cpu_baseline": cpu,
             "elbo_last_step": {"loss": final_loss[0], "reconstruction_loss": final_loss[1], "kld_loss": final_loss[2]},
         }
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

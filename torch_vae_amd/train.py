@@ -55,7 +55,7 @@ def allreduce_gradients(model: VanillaVAE, optimizer=None):
     """Sum the optimised gradient ranges over ranks (RCCL all-reduce over xGMI); the mean is applied
     inside the AdamW kernel (grad_scale = 1/world).  Returns the async work handles."""
     world = _dp_world()
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return []
     g = model.flat_grads()
     works = []
