@@ -64,6 +64,11 @@ int vae_forward(vae_ctx* ctx, const float* x, int batch, const float* params, fl
                 int64_t* num_batches_tracked, const float* eps, uint64_t seed, int train, float* xhat,
                 float* mu, float* log_var, float* z, vae_stream_t stream);
 
+/* VanillaVAE.decode (models.py:147-175): z [B,L] -> xhat [B,1,H,W].  train!=0 uses (and updates) batch
+ * statistics like a train-mode module call; the pass is not differentiable (vae_backward needs vae_forward). */
+int vae_decode(vae_ctx* ctx, const float* z, int batch, const float* params, float* bn_running,
+               int64_t* num_batches_tracked, int train, float* xhat, vae_stream_t stream);
+
 /* EncoderOutput.pre_latents (models.py:133, types_helpers.py:20) of the last forward,
  * [B, flattened_size] f32 in the reference's NCHW-flatten order. */
 int vae_pre_latents(vae_ctx* ctx, float* out, vae_stream_t stream);

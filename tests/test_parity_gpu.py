@@ -334,3 +334,52 @@ def test_pipelined_and_simple_conv_kernels_agree():
                 continue
             tol = 5e-3 if dtype == "f32" else 2e-2   # statistics are summed in a different order: kink ties / bf16 rounding ties may flip
             assert rel_l2(res[1][2][n], res[0][2][n]) < tol, (H, dtype, n)
+
+
+def test_decode_sample_evaluate_and_checkpoint(tmp_path):
+    """N2-N4 of SURVEY.md 8f: decode(z)/sample(), the forward-only evaluate() consumer, checkpoint round trip."""
+    from torch_vae_amd.evaluation import evaluate
+    from torch_vae_amd.optim import FusedAdamW
+    from torch_vae_amd.utils import safe_save_model
+    H, L, B, gen = 32, 16, 8, False
+    p = perturbed_params(L, H, 6, gen)
+    m = make_model(H, L, gen, "f32", p)
+    st = vo.init_bn_state()
+    x = vo.synth_pianoroll(B, H, 2)
+    eps = vo.counter_normal(B * L, 2, 5).reshape(B, L)
+    # decode(z) in eval mode == decoder half of the oracle forward
+    m.eval()
+    c = vo.forward(p, x.astype(np.float64), eps, st, train=False)
+    with torch.no_grad():
+        xd = m.decode(torch.from_numpy(c["zlat"]).float().cuda())
+    assert rel_l2(xd.cpu().numpy(), c["output"]) < 1e-4
+    s = m.sample(5, "cuda")
+    assert s.shape == (5, 1, H, H) and bool(((s >= 0) & (s <= 1)).all())
+    # evaluate(): count / mse / mae like evaluation.py:96-100
+    class DS(list):
+        pass
+    loader = [(torch.from_numpy(x[:4]), torch.zeros(4)), (torch.from_numpy(x[4:]), torch.zeros(4))]
+    m.set_next_eps(torch.from_numpy(eps[:4]).float().cuda())
+    res = evaluate(loader, m, "cuda", verbosity=0)
+    assert res["count"] == B and res["cross-entropy"] == 0.0 and 0 < res["mae"] < 100 and 0 < res["mse"] < 100
+    # checkpoint round trip in the reference's format (utils.py:311-351, train.py:444-460)
+    m.train()
+    opt = FusedAdamW([{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()}], lr=1e-3, weight_decay=0.0)
+    m.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+    opt.step()
+    path = str(tmp_path / "ckpt" / "model.pt")
+    safe_save_model({"encoder": m.encoder, "decoder": m.decoder, "optimizer": opt}, path, epoch=3)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) >= {"encoder", "decoder", "optimizer", "epoch"} and "0.0.weight" in ck["encoder"]
+    m2 = make_model(H, L, gen, "f32", p)
+    m2.encoder.load_state_dict(ck["encoder"]); m2.decoder.load_state_dict(ck["decoder"])
+    for (n, a), (_, b) in zip(m.encoder.state_dict().items(), m2.encoder.state_dict().items()):
+        assert torch.equal(a, b), n
+    opt2 = FusedAdamW([{"params": m2.encoder.parameters()}, {"params": m2.decoder.parameters()}], lr=1e-3, weight_decay=0.0)
+    opt2.load_state_dict(ck["optimizer"])
+    assert opt2._step == 1 and torch.equal(opt2._m, opt._m) and torch.equal(opt2._v, opt._v)
+    # flat views survived load_state_dict: one more fused step moves both models identically
+    for mm, oo in ((m, opt), (m2, opt2)):
+        mm.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+        oo.step()
+    assert rel_l2(m2.flat_parameters().cpu().numpy(), m.flat_parameters().cpu().numpy()) < 1e-6

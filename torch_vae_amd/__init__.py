@@ -17,6 +17,12 @@ def __getattr__(name):
     if name == "FusedAdamW":
         from .optim import FusedAdamW
         return FusedAdamW
+    if name == "evaluate":
+        from .evaluation import evaluate
+        return evaluate
+    if name == "safe_save_model":
+        from .utils import safe_save_model
+        return safe_save_model
     if name in ("train_one_epoch", "build_optimizer", "SyntheticPianorollLoader", "allreduce_gradients"):
         from . import train
         return getattr(train, name)

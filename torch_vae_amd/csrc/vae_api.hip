@@ -490,6 +490,54 @@ static int bn_finalize_fwd(vae_ctx* c, int i, const float* params, float* bn_run
     return 0;
 }
 
+// decoder half of the forward (models.py:147-175): decoder_input -> 3x ConvT blocks -> final_layer
+template <typename T>
+static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
+                       const float* x, float* xhat, hipStream_t st) {
+    const int H = c->H, L = c->L;
+    static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
+    c->tag = "latent";
+    // decoder_input
+    {
+        dim3 grid((unsigned)(c->F / 256), (B + 15) / 16);
+        ProfScope ps(c, "decin_fwd", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
+        hipLaunchKernelGGL((decin_fwd_kernel<T>), grid, dim3(256), 16 * L * 4, st, z, params + c->poff[20], params + c->poff[21],
+                           reinterpret_cast<T*>(c->d0), B, (int)c->F, L, c->s2);
+        LAUNCH_CHECK("decin_fwd_kernel");
+    }
+    for (int i = 4; i < 8; ++i) {
+        c->tag = kLayerTag[i];
+        ConvArgs<T> a; memset(&a, 0, sizeof(a));
+        if (i == 4) { a.src0 = reinterpret_cast<const T*>(c->d0); a.coef = c->ident; a.slope = 1.f; a.Cin = 256; }
+        else { a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope; a.Cin = c->lay[i - 1].C; }
+        a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
+        a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
+        a.B = B; a.Hs = c->lay[i].H / 2; a.Ws = c->lay[i].W / 2; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
+        if (launch_up<T>(c, a, st)) return -1;
+        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
+    }
+    // output conv + sigmoid + reconstruction loss/gradient
+    c->tag = "final_layer.3";
+    {
+        ConvOutArgs a;
+        a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
+        a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
+        a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
+        ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
+        if (sizeof(T) == 2 && c->use_mfma_convout) {
+            ConvOutFwdMfmaArgs m;
+            m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.coef = a.coef; m.wt = a.wt; m.bias = a.bias; m.target = x;
+            m.xhat = xhat; m.dlogit = c->dlogit; m.accum = c->accum; m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
+            m.inv_n = a.inv_n; m.slope = kSlope;
+            hipLaunchKernelGGL(convout_fwd_mfma_kernel, dim3(std::min(m.n_tiles, c->knob_convout_grid)), dim3(256), 0, st, m);
+        } else {
+            hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
+        }
+        LAUNCH_CHECK("convout_fwd_kernel");
+    }
+    return 0;
+}
+
 template <typename T>
 static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
                         const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, hipStream_t st) {
@@ -538,45 +586,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, la);
         LAUNCH_CHECK("latent_fwd_kernel");
     }
-    // decoder_input
-    {
-        dim3 grid((unsigned)(c->F / 256), (B + 15) / 16);
-        ProfScope ps(c, "decin_fwd", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
-        hipLaunchKernelGGL((decin_fwd_kernel<T>), grid, dim3(256), 16 * L * 4, st, z, params + c->poff[20], params + c->poff[21],
-                           reinterpret_cast<T*>(c->d0), B, (int)c->F, L, c->s2);
-        LAUNCH_CHECK("decin_fwd_kernel");
-    }
-    for (int i = 4; i < 8; ++i) {
-        c->tag = kLayerTag[i];
-        ConvArgs<T> a; memset(&a, 0, sizeof(a));
-        if (i == 4) { a.src0 = reinterpret_cast<const T*>(c->d0); a.coef = c->ident; a.slope = 1.f; a.Cin = 256; }
-        else { a.src0 = reinterpret_cast<const T*>(c->lay[i - 1].y); a.coef = c->lay[i - 1].block; a.slope = kSlope; a.Cin = c->lay[i - 1].C; }
-        a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
-        a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
-        a.B = B; a.Hs = c->lay[i].H / 2; a.Ws = c->lay[i].W / 2; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
-        if (launch_up<T>(c, a, st)) return -1;
-        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
-    }
-    // output conv + sigmoid + reconstruction loss/gradient
-    c->tag = "final_layer.3";
-    {
-        ConvOutArgs a;
-        a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
-        a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
-        a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
-        ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
-        if (sizeof(T) == 2 && c->use_mfma_convout) {
-            ConvOutFwdMfmaArgs m;
-            m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.coef = a.coef; m.wt = a.wt; m.bias = a.bias; m.target = x;
-            m.xhat = xhat; m.dlogit = c->dlogit; m.accum = c->accum; m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
-            m.inv_n = a.inv_n; m.slope = kSlope;
-            hipLaunchKernelGGL(convout_fwd_mfma_kernel, dim3(std::min(m.n_tiles, c->knob_convout_grid)), dim3(256), 0, st, m);
-        } else {
-            hipLaunchKernelGGL((convout_fwd_kernel<T>), dim3(B * (H / 16) * (H / 32)), dim3(256), 0, st, a);
-        }
-        LAUNCH_CHECK("convout_fwd_kernel");
-    }
-    return 0;
+    return decode_impl<T>(c, z, B, params, bn_running, nbt, train, x, xhat, st);
 }
 
 static int bn_finalize_bwd(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
@@ -750,6 +760,21 @@ extern "C" int vae_forward(vae_ctx* c, const float* x, int B, const float* param
     hipStream_t st = (hipStream_t)stream;
     return c->dtype == VAE_DTYPE_BF16 ? forward_impl<bf16>(c, x, B, params, bn_running, nbt, eps, seed, train, xhat, mu, lv, z, st)
                                       : forward_impl<float>(c, x, B, params, bn_running, nbt, eps, seed, train, xhat, mu, lv, z, st);
+}
+
+extern "C" int vae_decode(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
+                          float* xhat, vae_stream_t stream) {
+    if (!c) return vae_set_error("vae_decode", "null ctx");
+    if (B < 1 || B > c->maxB) return vae_set_error("vae_decode", "batch exceeds the context's max_batch");
+    if (!z || !params || !xhat) return vae_set_error("vae_decode", "null tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    c->B = B; c->trained = 0;   // a decode-only pass cannot be differentiated
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
+    int rc = c->dtype == VAE_DTYPE_BF16 ? pack_weights<bf16>(c, params, st) : pack_weights<float>(c, params, st);
+    if (rc) return rc;
+    // the reconstruction-loss side outputs of the output-conv kernel are unused here: xhat doubles as the target
+    return c->dtype == VAE_DTYPE_BF16 ? decode_impl<bf16>(c, z, B, params, bn_running, nbt, train, xhat, xhat, st)
+                                      : decode_impl<float>(c, z, B, params, bn_running, nbt, train, xhat, xhat, st);
 }
 
 extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {

@@ -385,10 +385,19 @@ class VanillaVAE(nn.Module):
         return out["encoded"]
 
     def decode(self, z: Tensor) -> Tensor:
-        """models.py:147-175.  Not part of the training hot path; served by the forward kernels with
-        the latent forced through mu (eps = 0, log_var ignored) is not possible without the encoder,
-        so decoding an arbitrary z is not implemented on this path."""
-        raise NotImplementedError("decode(z) of an arbitrary latent is outside the hot path (SURVEY.md 8f, N4)")
+        """models.py:147-175: latent [B, latent_dim] -> reconstruction [B,1,H,W].  Inference helper (SURVEY.md 8f,
+        N4): runs the decoder kernels only; not differentiable (training differentiates through forward())."""
+        self._require_device()
+        z = z.detach().to(self._flat.device, torch.float32).contiguous()
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise RuntimeError(f"expected z [B,{self.latent_dim}], got {tuple(z.shape)}")
+        B = z.shape[0]
+        ctx = self._context(B)
+        xhat = torch.empty(B, 1, self.img_size, self.img_size, device=z.device, dtype=torch.float32)
+        _lib.check(_lib.lib().vae_decode(ctx.handle, z.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(),
+                                        self._nbt.data_ptr(), int(self.training), xhat.data_ptr(), _stream_ptr()), "vae_decode")
+        self._last = None
+        return xhat
 
     def reparameterize(self, mu: Tensor, log_var: Tensor) -> Tensor:
         """models.py:177-183 (plumbing-level torch ops; the hot path fuses this into the latent kernel)."""
@@ -436,7 +445,10 @@ class VanillaVAE(nn.Module):
         return LossOutput(loss=loss, reconstruction_loss=out3[1].detach(), kld_loss=out3[2].detach())
 
     def sample(self, num_samples: int, current_device: int, **kwargs) -> Tensor:
-        raise NotImplementedError("sample() decodes arbitrary latents: outside the hot path (SURVEY.md 8f, N4)")
+        """models.py:250-263: z ~ N(0, I) on the host generator, moved to the device, decoded."""
+        z = torch.randn(num_samples, self.latent_dim)
+        z = z.to(current_device)
+        return self.decode(z)
 
     def generate(self, x: Tensor, **kwargs) -> Tensor:
         """models.py:265-272."""

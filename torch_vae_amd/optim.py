@@ -50,6 +50,26 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[o:o + n].view(p.shape),
                                  "exp_avg_sq": self._v[o:o + n].view(p.shape)}
 
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the state tensors; copy them back into the flat moment buffers."""
+        self._bind()
+        super().load_state_dict(state_dict)
+        model = self._model
+        step = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state.get(p, {})
+                o, n = model._offs[p._vae_index], model._sizes[p._vae_index]
+                for key, flat in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
+                    view = flat[o:o + n].view(p.shape)
+                    if key in st:
+                        view.copy_(st[key])
+                    st[key] = view
+                step = max(step, int(st.get("step", 0)))
+                st["step"] = torch.tensor(float(step))
+                self.state[p] = st
+        self._step = step
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
