@@ -1,0 +1,21 @@
+"""Diagnostic (GPU box): per-phase cycle shares of the pipelined down kernel for chosen layers."""
+import sys, os, json, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch_vae_amd import _lib
+from torch_vae_amd.models import VanillaVAE
+from torch_vae_amd.train import SyntheticPianorollLoader
+H, L, B = 128, 16, 256
+model = VanillaVAE(1, L, H, generalised=True, compute_dtype="bf16", max_batch=B).cuda()
+x = SyntheticPianorollLoader(B, H, 1, device="cuda").batch(0)[0]
+model.fused_forward_backward(x)
+Lb = _lib.lib(); Lb.vae_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+names = ["barrierA", "write_patch", "barrierB", "issue", "mfma", "epilogue"]
+for tag, epi in [("encoder.3", 0), ("encoder.1", 0), ("final_layer.0", 1), ("decoder.0", 2), ("decoder.1", 1)]:
+    buf = torch.zeros(768 * 4 * 6, dtype=torch.int64, device="cuda")
+    Lb.vae_debug_stamps(model._ctx.handle, tag.encode(), epi, buf.data_ptr())
+    model.fused_forward_backward(x); torch.cuda.synchronize()
+    Lb.vae_debug_stamps(model._ctx.handle, b"", 0, None)
+    t = buf.view(-1, 6).double(); t = t[t.sum(1) > 0]
+    tot = t.sum(1).mean().item()
+    print(f"{tag} epi={epi}: waves {t.shape[0]}, cycles/wave {tot:.0f} ->", {n: f"{100*t[:,k].mean().item()/tot:.0f}%" for k, n in enumerate(names)})

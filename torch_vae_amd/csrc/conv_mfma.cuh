@@ -34,6 +34,7 @@ template <typename T> struct ConvArgs {
     int lth, ltw, lTB, tiles_x, tiles_y;
     int two_src, epi;                                              // runtime: gradient-operand load / epilogue kind
     unsigned m_pp, m_pw, m_tx, m_txy;                              // fastdiv magics: PP, PW, tiles_x, tiles_x*tiles_y
+    long long* dbg;                                                // diagnostic builds only: per-wave phase cycle counters
 };
 
 // x / d for small x via one mul_hi: m = ceil(2^32 / d), exact for x, d < 2^16

@@ -129,8 +129,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) { issue(cur, 0); if (EPI == EPI_BWD) issue_y(cur); }
+    long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
+#define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
     while (have) {
         __syncthreads();                                   // (A) previous item fully consumed
+        STAMP(0)
         write_patch(cur, chunk * CK);
         if (EPI == EPI_BWD && chunk == 0) {
 #pragma unroll
@@ -139,13 +142,16 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                 *reinterpret_cast<decltype(Vec16<T>::v)*>(mytile + loff) = prey[u];
             }
         }
+        STAMP(1)
         __syncthreads();                                   // (B) patch published
+        STAMP(2)
         int npi = pi, nchunk = chunk + 1;
         TileGeo nxt = cur;
         if (nchunk == NCH) { nchunk = 0; npi += gridDim.x; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
         const bool nhave = npi < n_pairs;
         if (nhave) issue(nxt, nchunk * CK);                // in flight during the MFMAs / epilogue below
 
+        STAMP(3)
         const int c0 = chunk * CK;
         {
             // weights straight from L1/L2 as the B operand, kept two taps ahead of the matrix pipe
@@ -161,20 +167,28 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             };
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) load_b(d, d);
+            // A fragments one (tap, k-step) ahead of the matrix pipe
+            auto load_a = [&](int step) __attribute__((always_inline)) {
+                const int t = step / KS, ks = step % KS;
+                return load_frag(reinterpret_cast<const T*>(patch + (pbase + (t / 3) * PW + (t % 3)) * PATCH_PITCH + ks * 32) + h * 8);
+            };
+            Frag<T> af = load_a(0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const T* ap = reinterpret_cast<const T*>(patch + (pbase + (t / 3) * PW + (t % 3)) * PATCH_PITCH + ks * 32) + h * 8;
-                    Frag<T> af = load_frag(ap);
+                    const int step = t * KS + ks;
+                    Frag<T> afn = af;
+                    if (step + 1 < 9 * KS) afn = load_a(step + 1);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mma(acc[nt], af, bq[t % DEPTH][ks][nt]);
+                    af = afn;
                 }
-                if (t + DEPTH < 9) load_b(t + DEPTH, t % DEPTH);
-                __builtin_amdgcn_sched_barrier(0);
+                if (t + DEPTH < 9 && !(a.two_src & 2)) load_b(t + DEPTH, t % DEPTH);
             }
         }
 
+        STAMP(4)
         if (chunk == NCH - 1) {
             if (nhave && nchunk == 0 && EPI == EPI_BWD) issue_y(nxt);
             // ---- epilogue through the wave-private LDS tile
@@ -215,8 +229,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                 if (gi >= 0) *reinterpret_cast<Vec16<T>*>(a.out + gi) = v;
             }
         }
+        STAMP(5)
         pi = npi; chunk = nchunk; cur = nxt; have = nhave;
     }
+    if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
+#undef STAMP
 
     if (EPI != EPI_PLAIN) {
         // all (M tile, N tile) pairs of one workgroup may span several N tiles: statistics are kept per

@@ -93,7 +93,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_nt_max, knob_pipe_max_cout; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_nt_max, knob_pipe_max_cout, knob_ablate_b; long long* dbg_buf; char dbg_tag[32]; int dbg_epi; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -148,7 +148,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -227,6 +227,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_convout_grid")) { c->knob_convout_grid = value; return 0; }
     if (!strcmp(name, "knob_nt_max")) { c->knob_nt_max = value; return 0; }
     if (!strcmp(name, "knob_pipe_max_cout")) { c->knob_pipe_max_cout = value; return 0; }
+    if (!strcmp(name, "knob_ablate_b")) { c->knob_ablate_b = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -305,17 +306,19 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     const size_t opitch = 32 * NT * sizeof(T) + 16;
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
                        (size_t)TB * PHW * 4 * 8;   // + the per-item staging table
-    if (a.two_src && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
+    if (c->knob_ablate_b) a.two_src |= 2;
+    a.dbg = (c->dbg_buf && is_down && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == c->dbg_epi) ? c->dbg_buf : nullptr;
+    if ((a.two_src & 1) && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
     int grid = std::min(n_pairs, 256 * per_cu);
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
     const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
     const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
     ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
-                 sizeof(T) * (px_in * a.Cin * (a.two_src ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
+                 sizeof(T) * (px_in * a.Cin * ((a.two_src & 1) ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
                  2.0 * 9 * a.Cin * a.Cout * px_lo, st);
 #define PIPE_CASE(K, N, W) { if (set_lds(K<T, N, W>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
-#define PIPE_SRC(K, N) { if (a.two_src) PIPE_CASE(K, N, true) else PIPE_CASE(K, N, false) }
+#define PIPE_SRC(K, N) { if (a.two_src & 1) PIPE_CASE(K, N, true) else PIPE_CASE(K, N, false) }
     if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else if (NT == 2) PIPE_SRC(down2_kernel, 2) else if (NT == 4) PIPE_SRC(down2_kernel, 4) else PIPE_SRC(down2_kernel, 8) }
     else { if (NT == 1) PIPE_SRC(up2_kernel, 1) else PIPE_SRC(up2_kernel, 2) }
 #undef PIPE_SRC
@@ -833,6 +836,13 @@ extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, 
     if (vae_loss(c, kld_weight, out3, stream)) return -1;
     if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
     if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, 1.f, step, stream)) return -1;
+    return 0;
+}
+
+// diagnostic: phase stamps of the pipelined down kernel for one layer ("encoder.3", epi) into out[grid*4*6]
+extern "C" int vae_debug_stamps(vae_ctx* c, const char* tag, int epi, long long* out) {
+    if (!c) return -1;
+    c->dbg_buf = out; c->dbg_epi = epi; strncpy(c->dbg_tag, tag ? tag : "", sizeof(c->dbg_tag) - 1);
     return 0;
 }
 
