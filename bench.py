@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (path test)")
+    ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE", help="vae_set_option knob (diagnostics)")
     ap.add_argument("--dump-order", default=None, help="write the per-step launch order (label, kernel symbol) as JSON")
     return ap.parse_args()
 
@@ -74,6 +75,9 @@ def main():
     gen = H != 32
     torch.manual_seed(0)  # identical initial weights on every rank
     model = VanillaVAE(1, L, H, generalised=gen, compute_dtype=args.dtype, max_batch=B).to(dev)
+    for kv in args.set:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().vae_set_option(model._context(B).handle, k.encode(), int(v)), "vae_set_option")
     total_steps = args.steps + args.warmup + 8
     cfg = Namespace(batch_size_per_gpu=B, world_size=world, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW",
                     scheduler="OneCycle", epochs=1, freeze_encoder=False)

@@ -10,6 +10,8 @@ model = VanillaVAE(1, L, H, generalised=True, compute_dtype="bf16", max_batch=B)
 x = SyntheticPianorollLoader(B, H, 1, device="cuda").batch(0)[0]
 model.fused_forward_backward(x)
 Lb = _lib.lib(); Lb.vae_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+for k, v in (json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}).items():
+    assert Lb.vae_set_option(model._ctx.handle, k.encode(), v) == 0
 names = ["barrierA", "write_patch", "barrierB", "issue", "mfma", "epilogue"]
 for tag, epi in [("encoder.3", 0), ("encoder.1", 0), ("final_layer.0", 1), ("decoder.0", 2), ("decoder.1", 1)]:
     buf = torch.zeros(768 * 4 * 6, dtype=torch.int64, device="cuda")

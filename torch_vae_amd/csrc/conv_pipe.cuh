@@ -25,20 +25,26 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int NT, bool TWO_SRC>
+// WV = wave-independent mode: every wave owns a 32-pixel M tile with its own patch / out tile in LDS and walks
+// its own sequence of tiles; no workgroup barrier inside the persistent loop (LDS traffic of one wave is
+// processed in order), so the 8 waves of a CU sit in different phases and cover each other's stalls.
+template <typename T, int NT, bool TWO_SRC, bool WV>
 __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 10;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;   // out-tile row bytes / chunks
     constexpr int OPL = OCH / 2;                                                     // out chunks per lane (32 px per wave)
     const int EPI = a.epi;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
+    constexpr int SSTR = WV ? 64 : 256;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP, nitems = npix * 4;
     const int Hin = 2 * a.Hs, Win = 2 * a.Ws, Cin = a.Cin, Cout = a.Cout, NCH = Cin / CK;
     float* cf = reinterpret_cast<float*>(smem);
-    char* patch = smem + ((3 * Cin * 4 + 15) & ~15);
-    char* otile = patch + npix * PATCH_PITCH;                 // [4 waves][32 px][OPITCH]
+    char* patch0 = smem + ((3 * Cin * 4 + 15) & ~15);
+    char* patch = patch0 + (WV ? wave * npix * PATCH_PITCH : 0);
+    char* otile = patch0 + (WV ? 4 : 1) * npix * PATCH_PITCH;                 // [4 waves][32 px][OPITCH]
     float* red = reinterpret_cast<float*>(otile + 128 * OPITCH);
     char* mytile = otile + wave * 32 * OPITCH;
     // per-item staging table (tile-independent): {relative global element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
 
-    const int R = wave * 32 + r;
+    const int R = wv0 * 32 + r;
     const int pbase = ((R >> (a.lth + a.ltw)) * PH + 2 * ((R >> a.ltw) & (th - 1))) * PW + 2 * (R & (tw - 1));
 
     f32x16 acc[NT];
@@ -64,53 +70,75 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
     }
 
+    // a thread always stages the same 16-byte quarter of a pixel (stid & 3): its per-channel coefficients live in
+    // registers, reloaded only when the channel chunk changes
+    constexpr int NE = Vec16<T>::N;
+    float k0[NE], k1[TWO_SRC ? NE : 1], k2[NE];
+    auto load_coefs = [&](int c0) __attribute__((always_inline)) {
+        const int cb = c0 + (stid & 3) * E16;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            k0[e] = cf[cb + e]; k2[e] = cf[2 * Cin + cb + e];
+            if constexpr (TWO_SRC) k1[e] = cf[Cin + cb + e];
+        }
+    };
+    auto xform = [&](const Vec16<T>& v0, const Vec16<T>& v1) __attribute__((always_inline)) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (TWO_SRC) o.set(e, v0.get(e) * k0[e] + v1.get(e) * k1[e] + k2[e]);
+            else o.set(e, leaky(v0.get(e) * k0[e] + k2[e], a.slope));
+        }
+        return o;
+    };
     Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1];
     decltype(Vec16<T>::v) prey[OPL];   // raw vectors: keeps the prefetch in VGPRs (a struct array was demoted to scratch)
 
-    // item -> (LDS offset, validity, global offset); recomputed where needed instead of kept in registers:
-    // any spilled dword is reloaded through scratch, whose loads share vmcnt with the prefetch burst.
-    auto item_geo = [&](const TileGeo& g, int c0, int it, int& loff, bool& ok, size_t& gi) __attribute__((always_inline)) {
-        const int2 e = itab[it < nitems ? it : 0];
+    // item -> (LDS offset, validity, global offset) from the LDS table; recomputed where needed instead of kept in
+    // registers.  Offsets are 32-bit element indices (the launcher checks the tensors are < 2^31 elements), so the
+    // loads use the scalar-base + 32-bit-offset form and validity is a select, not a branch.
+    auto tile_base = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        return ((g.b0 * Hin + 2 * g.y0 - 1) * Win + 2 * g.x0 - 1) * Cin + c0;
+    };
+    auto item_ok = [&](const TileGeo& g, int it, int ey) __attribute__((always_inline)) {
         // the halo row/column (py==0 / px==0) falls outside the image only for tiles on the top / left border
-        ok = (it < nitems) & ((g.b0 + (e.y >> 15)) < a.B) & !(((e.y >> 13) & 1) & (g.y0 == 0)) & !(((e.y >> 14) & 1) & (g.x0 == 0));
-        loff = (e.y & 0x1fff) << 4;
-        const long base = (((long)g.b0 * Hin + 2 * g.y0 - 1) * Win + 2 * g.x0 - 1) * Cin + c0;
-        gi = ok ? (size_t)(base + e.x) : 0;
+        return (it < nitems) & ((g.b0 + (ey >> 15)) < a.B) & !(((ey >> 13) & 1) & (g.y0 == 0)) & !(((ey >> 14) & 1) & (g.x0 == 0));
     };
     auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        const int base = tile_base(g, c0);
+        int2 e[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it < nitems ? it : 0]; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, tid + u * 256, loff, ok, gi);
+            const uint32_t gi = item_ok(g, stid + u * SSTR, e[u].y) ? (uint32_t)(base + e[u].x) : 0u;
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
         }
     };
     auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        int ey[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it < nitems ? it : 0].y; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int it = tid + u * 256;
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, it, loff, ok, gi);
-            if (it < nitems) {
-                // chunk quarter q = item & 3 (256 % 4 == 0), so the first channel of the chunk is c0 + q*E16
-                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + (it & 3) * E16, a.slope);
-                if (!ok) o = zero_vec16<T>();
-                *reinterpret_cast<Vec16<T>*>(patch + loff) = o;
-            }
+            const int it = stid + u * SSTR;
+            Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
+            if (!item_ok(g, it, ey[u])) o = zero_vec16<T>();
+            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((ey[u] & 0x1fff) << 4)) = o;
         }
-        // patches larger than MAXI*256 chunks (tiny spatial sizes, many images per tile): synchronous tail
-        for (int it = tid + MAXI * 256; it < nitems; it += 256) {
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, it, loff, ok, gi);
+        // patches larger than MAXI*SSTR chunks (tiny spatial sizes, many images per tile): synchronous tail
+        for (int it = stid + MAXI * SSTR; it < nitems; it += SSTR) {
+            const int2 e = itab[it];
+            const bool ok = item_ok(g, it, e.y);
             Vec16<T> v = zero_vec16<T>();
-            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + (it & 3) * E16, a.slope);
-            *reinterpret_cast<Vec16<T>*>(patch + loff) = v;
+            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, (size_t)(tile_base(g, c0) + e.x), cf, Cin, c0 + (it & 3) * E16, a.slope);
+            *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
         }
     };
     // global element offset of out-tile chunk (wave-local chunk id) or -1
     auto out_chunk_addr = [&](const TileGeo& g, int id, int& loff) __attribute__((always_inline)) -> long {
-        const int row = id / OCH, qq = id - row * OCH, RR = wave * 32 + row;
+        const int row = id / OCH, qq = id - row * OCH, RR = wv0 * 32 + row;
         loff = row * OPITCH + qq * 16;
         const int b = g.b0 + (RR >> (a.lth + a.ltw));
         if (b >= a.B) return -1;
@@ -125,15 +153,20 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         }
     };
 
-    int pi = blockIdx.x, chunk = 0;
+    // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
+    int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
+    const int pstride = WV ? 4 * gridDim.x : gridDim.x;
+    __syncthreads();                                       // staging table / coefficients published
+    load_coefs(0);
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) { issue(cur, 0); if (EPI == EPI_BWD) issue_y(cur); }
     long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
 #define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
     while (have) {
-        __syncthreads();                                   // (A) previous item fully consumed
+        if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A) previous item fully consumed
         STAMP(0)
+        if (NCH > 1) load_coefs(chunk * CK);
         write_patch(cur, chunk * CK);
         if (EPI == EPI_BWD && chunk == 0) {
 #pragma unroll
@@ -143,11 +176,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             }
         }
         STAMP(1)
-        __syncthreads();                                   // (B) patch published
+        if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B) patch published
         STAMP(2)
         int npi = pi, nchunk = chunk + 1;
         TileGeo nxt = cur;
-        if (nchunk == NCH) { nchunk = 0; npi += gridDim.x; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
+        if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
         const bool nhave = npi < n_pairs;
         if (nhave) issue(nxt, nchunk * CK);                // in flight during the MFMAs / epilogue below
 
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = acc_row(i, lane), RR = wave * 32 + row;
+                    const int row = acc_row(i, lane), RR = wv0 * 32 + row;
                     const bool valid = (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B;
                     T* cell = reinterpret_cast<T*>(mytile + row * OPITCH) + nt * 32 + r;
                     if (EPI == EPI_FWD) {
@@ -258,20 +291,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int NT, bool TWO_SRC>
+template <typename T, int NT, bool TWO_SRC, bool WV>
 __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 3;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;
     constexpr int OPL = OCH;                          // 64 output pixels per wave per round (32 base px x 2 x-parities)
     const int EPI = a.epi;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
+    constexpr int SSTR = WV ? 64 : 256;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = th + 1, PW = tw + 1, PP = PH * PW, npix = TB * PP, nitems = npix * 4;
     const int Hs = a.Hs, Ws = a.Ws, Cin = a.Cin, Cout = a.Cout, NCH = Cin / CK;
     float* cf = reinterpret_cast<float*>(smem);
-    char* patch = smem + ((3 * Cin * 4 + 15) & ~15);
-    char* otile = patch + npix * PATCH_PITCH;                 // [4 waves][64 px][OPITCH]
+    char* patch0 = smem + ((3 * Cin * 4 + 15) & ~15);
+    char* patch = patch0 + (WV ? wave * npix * PATCH_PITCH : 0);
+    char* otile = patch0 + (WV ? 4 : 1) * npix * PATCH_PITCH;                 // [4 waves][64 px][OPITCH]
     float* red = reinterpret_cast<float*>(otile + 256 * OPITCH);
     char* mytile = otile + wave * 64 * OPITCH;
     // per-item staging table: {relative global element offset, LDS offset/16 | row<<13 | col<<19 | img<<25}
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
 
     for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
 
-    const int R = wave * 32 + r;
+    const int R = wv0 * 32 + r;
     const int pbase = ((R >> (a.lth + a.ltw)) * PH + ((R >> a.ltw) & (th - 1))) * PW + (R & (tw - 1));
 
     f32x16 acc[4][NT];
@@ -303,49 +339,71 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
     constexpr int tap_t[NTAP] = {4, 5, 3, 7, 1, 8, 6, 2, 0};
     constexpr int tap_off[NTAP] = {0, 0, 1, 0, 2, 0, 1, 2, 3};  // di*2+dj
 
+    // a thread always stages the same 16-byte quarter of a pixel (stid & 3): its per-channel coefficients live in
+    // registers, reloaded only when the channel chunk changes
+    constexpr int NE = Vec16<T>::N;
+    float k0[NE], k1[TWO_SRC ? NE : 1], k2[NE];
+    auto load_coefs = [&](int c0) __attribute__((always_inline)) {
+        const int cb = c0 + (stid & 3) * E16;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            k0[e] = cf[cb + e]; k2[e] = cf[2 * Cin + cb + e];
+            if constexpr (TWO_SRC) k1[e] = cf[Cin + cb + e];
+        }
+    };
+    auto xform = [&](const Vec16<T>& v0, const Vec16<T>& v1) __attribute__((always_inline)) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if constexpr (TWO_SRC) o.set(e, v0.get(e) * k0[e] + v1.get(e) * k1[e] + k2[e]);
+            else o.set(e, leaky(v0.get(e) * k0[e] + k2[e], a.slope));
+        }
+        return o;
+    };
     Vec16<T> pre0[MAXI], pre1[TWO_SRC ? MAXI : 1];
     decltype(Vec16<T>::v) prey[OPL];
 
-    auto item_geo = [&](const TileGeo& g, int c0, int it, int& loff, bool& ok, size_t& gi) __attribute__((always_inline)) {
-        const int2 e = itab[it < nitems ? it : 0];
+    auto tile_base = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        return ((g.b0 * Hs + g.y0) * Ws + g.x0) * Cin + c0;
+    };
+    auto item_ok = [&](const TileGeo& g, int it, int ey) __attribute__((always_inline)) {
         // the bottom/right halo (row th, column tw) leaves the image only on the last tile row / column
-        ok = (it < nitems) & ((g.b0 + (e.y >> 25)) < a.B) & ((g.y0 + ((e.y >> 13) & 63)) < Hs) & ((g.x0 + ((e.y >> 19) & 63)) < Ws);
-        loff = (e.y & 0x1fff) << 4;
-        const long base = (((long)g.b0 * Hs + g.y0) * Ws + g.x0) * Cin + c0;
-        gi = ok ? (size_t)(base + e.x) : 0;
+        return (it < nitems) & ((g.b0 + (ey >> 25)) < a.B) & ((g.y0 + ((ey >> 13) & 63)) < Hs) & ((g.x0 + ((ey >> 19) & 63)) < Ws);
     };
     auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        const int base = tile_base(g, c0);
+        int2 e[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it < nitems ? it : 0]; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, tid + u * 256, loff, ok, gi);
+            const uint32_t gi = item_ok(g, stid + u * SSTR, e[u].y) ? (uint32_t)(base + e[u].x) : 0u;
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
         }
     };
     auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
+        int ey[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it < nitems ? it : 0].y; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int it = tid + u * 256;
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, it, loff, ok, gi);
-            if (it < nitems) {
-                Vec16<T> o = transform16<T>(pre0[u], pre1[TWO_SRC ? u : 0], TWO_SRC, cf, Cin, c0 + (it & 3) * E16, a.slope);
-                if (!ok) o = zero_vec16<T>();
-                *reinterpret_cast<Vec16<T>*>(patch + loff) = o;
-            }
+            const int it = stid + u * SSTR;
+            Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
+            if (!item_ok(g, it, ey[u])) o = zero_vec16<T>();
+            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((ey[u] & 0x1fff) << 4)) = o;
         }
-        for (int it = tid + MAXI * 256; it < nitems; it += 256) {
-            int loff; bool ok; size_t gi;
-            item_geo(g, c0, it, loff, ok, gi);
+        for (int it = stid + MAXI * SSTR; it < nitems; it += SSTR) {
+            const int2 e = itab[it];
+            const bool ok = item_ok(g, it, e.y);
             Vec16<T> v = zero_vec16<T>();
-            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, gi, cf, Cin, c0 + (it & 3) * E16, a.slope);
-            *reinterpret_cast<Vec16<T>*>(patch + loff) = v;
+            if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, (size_t)(tile_base(g, c0) + e.x), cf, Cin, c0 + (it & 3) * E16, a.slope);
+            *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
         }
     };
     // round py: wave-local out pixel o = 2*row + px (row = base pixel 0..31) -> LDS row o, global (2i+py, 2j+px)
     auto out_chunk_addr = [&](const TileGeo& g, int py, int id, int& loff) __attribute__((always_inline)) -> long {
-        const int o = id / OCH, qq = id - o * OCH, row = o >> 1, px = o & 1, RR = wave * 32 + row;
+        const int o = id / OCH, qq = id - o * OCH, row = o >> 1, px = o & 1, RR = wv0 * 32 + row;
         loff = o * OPITCH + qq * 16;
         const int b = g.b0 + (RR >> (a.lth + a.ltw));
         if (b >= a.B) return -1;
@@ -375,17 +433,22 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
             }
         }
     }
-    int pi = blockIdx.x, chunk = 0;
+    // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
+    int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
+    const int pstride = WV ? 4 * gridDim.x : gridDim.x;
+    __syncthreads();                                       // staging table / coefficients published
+    load_coefs(0);
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) issue(cur, 0);
     while (have) {
-        __syncthreads();                                   // (A)
+        if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A)
+        if (NCH > 1) load_coefs(chunk * CK);
         write_patch(cur, chunk * CK);
-        __syncthreads();                                   // (B)
+        if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B)
         int npi = pi, nchunk = chunk + 1;
         TileGeo nxt = cur;
-        if (nchunk == NCH) { nchunk = 0; npi += gridDim.x; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
+        if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
         const bool nhave = npi < n_pairs;
         if (nhave) issue(nxt, nchunk * CK);
         if (chunk == NCH - 1 && EPI == EPI_BWD) issue_y(cur, 0);   // rows of round 0, hidden behind the MFMAs
@@ -434,7 +497,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
                     for (int px = 0; px < 2; ++px) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const int row = acc_row(i, lane), RR = wave * 32 + row;
+                            const int row = acc_row(i, lane), RR = wv0 * 32 + row;
                             const bool valid = (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B;
                             T* cell = reinterpret_cast<T*>(mytile + (2 * row + px) * OPITCH) + nt * 32 + r;
                             const float av = acc[py * 2 + px][nt][i];

@@ -89,7 +89,8 @@ struct vae_ctx {
     void* wp_fwd[8]; void* wp_dg[8];   // indexed by BN layer id (1..7); [0] unused
     void *fcpack, *dipack;
     PackDesc* d_descs; std::vector<PackDesc> h_descs; const float* packed_for;
-    float* slab; size_t slab_floats;
+    float* slab; float* slab2; size_t slab_floats;
+    hipStream_t side; hipEvent_t ev_fork, ev_join, ev_pack; int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -122,6 +123,7 @@ template <typename T> static T* dalloc(vae_ctx* c, size_t n) {
 extern "C" void vae_destroy(vae_ctx* c) {
     if (!c) return;
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_pack); }
     delete c;
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
@@ -148,7 +150,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 1; c->side = nullptr; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -208,8 +210,12 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_di);
         slab = std::max(slab, (size_t)8 * (2 * (size_t)L * c->F + c->F));   // fc / decoder_input weight-gradient batch slices
         c->slab_floats = slab;
-        c->slab = dalloc<float>(c, slab);
-        ok = c->slab != nullptr;
+        c->slab = dalloc<float>(c, slab); c->slab2 = dalloc<float>(c, slab);
+        ok = c->slab != nullptr && c->slab2 != nullptr;
+        if (ok) ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { vae_set_error("vae_create", "hipMalloc failed"); vae_destroy(c); return nullptr; }
     std::vector<float> id(3 * 256, 0.f);
@@ -228,6 +234,9 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_nt_max")) { c->knob_nt_max = value; return 0; }
     if (!strcmp(name, "knob_pipe_max_cout")) { c->knob_pipe_max_cout = value; return 0; }
     if (!strcmp(name, "knob_ablate_b")) { c->knob_ablate_b = value; return 0; }
+    if (!strcmp(name, "use_side_stream")) { c->use_side_stream = value; return 0; }
+    if (!strcmp(name, "knob_bwd_per_cu")) { c->knob_bwd_per_cu = value; return 0; }
+    if (!strcmp(name, "knob_wave_nt_max")) { c->knob_wave_nt_max = value; return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -242,10 +251,12 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 }
 
 template <typename T> static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st);
+// the pipelined kernels index their tensors with 32-bit element offsets
+template <typename T> static bool fits_i32(const ConvArgs<T>& a) { return 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) < 2147483648.0; }
 
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
-    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout) return launch_conv_pipe<T>(c, a, true, st);
+    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, true, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -267,7 +278,7 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 
 template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
-    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout) return launch_conv_pipe<T>(c, a, false, st);
+    if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, false, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -290,38 +301,44 @@ static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 // persistent, prefetched variants (conv_pipe.cuh)
 template <typename T>
 static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st) {
-    Tiling t = make_tiling(a.Hs, a.Ws, 128);
+    // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
+    int NT = std::min(c->knob_nt_max, a.Cout / 32);
+    NT = NT >= 8 ? 8 : (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1));
+    if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
+    if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
+    // wave-independent tiles (32 pixels per wave, no workgroup barrier in the loop) vs one 128-pixel tile per workgroup
+    const bool wv = sizeof(T) == 2 && NT <= c->knob_wave_nt_max;
+    Tiling t = make_tiling(a.Hs, a.Ws, wv ? 32 : 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     const int n_mt = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
     const int PHW = is_down ? (2 * th + 1) * (2 * tw + 1) : (th + 1) * (tw + 1);
     a.m_pp = fastdiv_magic(PHW); a.m_pw = fastdiv_magic(is_down ? 2 * tw + 1 : tw + 1);
     a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
-    // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
-    int NT = std::min(c->knob_nt_max, a.Cout / 32);
-    NT = NT >= 8 ? 8 : (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1));
-    if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
-    if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
-    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
                        (size_t)TB * PHW * 4 * 8;   // + the per-item staging table
+    if (lds > 160 * 1024) return vae_set_error("conv_pipe", "tile does not fit LDS");
     if (c->knob_ablate_b) a.two_src |= 2;
     a.dbg = (c->dbg_buf && is_down && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == c->dbg_epi) ? c->dbg_buf : nullptr;
     if ((a.two_src & 1) && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
-    int grid = std::min(n_pairs, 256 * per_cu);
+    const int n_wg_pairs = wv ? ((n_mt + 3) / 4) * ntn : n_pairs;    // workgroup-level work items
+    int grid = std::min(n_wg_pairs, 256 * ((c->knob_bwd_per_cu > 0 && a.epi != EPI_FWD) ? std::min(per_cu, c->knob_bwd_per_cu) : per_cu));
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
     const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
     const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
     ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
                  sizeof(T) * (px_in * a.Cin * ((a.two_src & 1) ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
                  2.0 * 9 * a.Cin * a.Cout * px_lo, st);
-#define PIPE_CASE(K, N, W) { if (set_lds(K<T, N, W>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
-#define PIPE_SRC(K, N) { if (a.two_src & 1) PIPE_CASE(K, N, true) else PIPE_CASE(K, N, false) }
+#define PIPE_CASE(K, N, W, V) { if (set_lds(K<T, N, W, V>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W, V>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
+#define PIPE_WV(K, N, W) { if (wv) PIPE_CASE(K, N, W, true) else PIPE_CASE(K, N, W, false) }
+#define PIPE_SRC(K, N) { if (a.two_src & 1) PIPE_WV(K, N, true) else PIPE_WV(K, N, false) }
     if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else if (NT == 2) PIPE_SRC(down2_kernel, 2) else if (NT == 4) PIPE_SRC(down2_kernel, 4) else PIPE_SRC(down2_kernel, 8) }
     else { if (NT == 1) PIPE_SRC(up2_kernel, 1) else PIPE_SRC(up2_kernel, 2) }
 #undef PIPE_SRC
+#undef PIPE_WV
 #undef PIPE_CASE
     LAUNCH_CHECK("conv_pipe_kernel");
     return 0;
@@ -334,7 +351,8 @@ static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int
 }
 
 template <typename T>
-static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st) {
+static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st, float* slab_buf = nullptr) {
+    if (!slab_buf) slab_buf = c->slab;
     int nsplit, tps, WA, WB;
     const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB);
     if (need > c->slab_floats) return vae_set_error("wgrad", "slab too small");
@@ -342,7 +360,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
-    a.slab = c->slab; a.use_tr16 = c->use_tr16;
+    a.slab = slab_buf; a.use_tr16 = c->use_tr16;
     a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int WK = 4 / (WA * WB);
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
@@ -367,7 +385,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     LAUNCH_CHECK("wgrad_kernel");
     }
     (void)WK;
-    return launch_reduce(c->slab, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
+    return launch_reduce(slab_buf, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
 }
 
 template <typename T>
@@ -494,6 +512,20 @@ static int bn_finalize_fwd(vae_ctx* c, int i, const float* params, float* bn_run
 }
 
 // decoder half of the forward (models.py:147-175): decoder_input -> 3x ConvT blocks -> final_layer
+// Weight gradients are consumed only by the optimiser: with use_side_stream they run on the context's side
+// stream (own slab buffer), forked from the caller's stream at the point their inputs are ready, while the
+// input-gradient chain - the critical path of the backward - continues on the caller's stream; the two are
+// joined at the end of vae_backward.  fork_side returns the stream (and slab) the forked work should use.
+struct SideFork { hipStream_t st; float* slab; int rc; };
+static SideFork fork_side(vae_ctx* c, hipStream_t st) {
+    SideFork f{st, c->slab, 0};
+    if (!c->use_side_stream) return f;
+    if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) {
+        f.rc = vae_set_error("fork_side", "event record/wait failed"); return f;
+    }
+    f.st = c->side; f.slab = c->slab2;
+    return f;
+}
 template <typename T>
 static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
                        const float* x, float* xhat, hipStream_t st) {
@@ -547,10 +579,15 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     const int H = c->H, L = c->L;
     c->B = B; c->trained = train; c->x = x; c->xhat = xhat; c->mu = mu; c->lv = lv; c->z = z;
     HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
-    if (pack_weights<T>(c, params, st)) return -1;
     static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
-    // encoder block 0
+    // encoder block 0 (reads the raw f32 weights); the MFMA layers' packed weight images are built meanwhile
     c->tag = kLayerTag[0];
+    {
+        SideFork f = fork_side(c, st);
+        if (f.rc) return f.rc;
+        if (pack_weights<T>(c, params, f.st)) return -1;
+        if (c->use_side_stream) HIP_CHECK_RET(hipEventRecord(c->ev_pack, c->side));
+    }
     {
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);   // few workgroups: one f64 atomic per channel each
@@ -559,6 +596,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
         LAUNCH_CHECK("conv1_fwd_kernel");
         if (bn_finalize_fwd(c, 0, params, bn_running, nbt, train, st)) return -1;
+        if (c->use_side_stream) HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_pack, 0));
     }
     for (int i = 1; i < 4; ++i) {
         c->tag = kLayerTag[i];
@@ -604,6 +642,13 @@ static int bn_finalize_bwd(vae_ctx* c, int i, const float* params, float* grads,
 }
 
 template <typename T>
+static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t st) {
+    SideFork f = fork_side(c, st);
+    if (f.rc) return f.rc;
+    return launch_wgrad<T>(c, w, dw_out, f.st, f.slab);
+}
+
+template <typename T>
 static int backward_impl(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
                          const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
                          hipStream_t st) {
@@ -625,26 +670,32 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // output conv backward + final_layer BN/LeakyReLU prologue
     c->tag = "final_layer.3";
+    int cgrid = 0;
     {
         ConvOutBwdArgs a;
         a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
-        a.dz = c->lay[7].dz; a.slab = c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
+        a.dz = c->lay[7].dz; a.slab = c->use_side_stream ? c->slab2 : c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
         const long P = (long)B * H * H;
         int grid = (int)std::min<long>((P + 63) / 64, 1024);
         ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
         if (sizeof(T) == 2 && c->use_mfma_convout) {
             ConvOutBwdMfmaArgs m;
             m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.ocoef = a.ocoef; m.wt = a.wt; m.dlogit = a.dlogit; m.gscale = a.gscale;
-            m.dz = reinterpret_cast<bf16*>(c->lay[7].dz); m.slab = c->slab; m.stat = a.stat; m.dbias = a.dbias;
+            m.dz = reinterpret_cast<bf16*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat; m.dbias = a.dbias;
             m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32); m.slope = kSlope;
             grid = std::min(m.n_tiles, c->knob_convout_grid);
             hipLaunchKernelGGL(convout_bwd_mfma_kernel, dim3(grid), dim3(256), 0, st, m);
         } else {
             hipLaunchKernelGGL((convout_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, a);
         }
+        cgrid = grid;
         LAUNCH_CHECK("convout_bwd_kernel");
-        if (launch_reduce(c->slab, grid, 288, grads + c->poff[38], 1, 32, st)) return -1;
-        hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st, c->accum + 2, grads + c->poff[39], 1, 1.f);
+    }
+    {
+        SideFork f = fork_side(c, st);
+        if (f.rc) return f.rc;
+        if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st)) return -1;
+        hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39], 1, 1.f);
         LAUNCH_CHECK("d2f_kernel");
     }
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
@@ -659,7 +710,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         w.s_two = 0;
         w.g0 = reinterpret_cast<const T*>(l.dz); w.g1 = reinterpret_cast<const T*>(l.y); w.gcoef = l.block + LC_P0 * l.C; w.gslope = 1.f; w.g_two = 1;
         w.B = B; w.Hs = l.H / 2; w.Ws = l.W / 2; w.CA = Cin; w.CB = l.C;
-        if (launch_wgrad<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
         a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
@@ -677,13 +728,15 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         {
             // batch split over grid.z (8 slices) -> slabs -> one reduce per tensor
             const int nz = std::max(1, std::min(8, B / 8)), bsplit = (B + nz - 1) / nz;
-            float* sw = c->slab; float* sb = c->slab + (size_t)nz * c->F * L;
+            SideFork f = fork_side(c, st);
+            if (f.rc) return f.rc;
+            float* sw = f.slab; float* sb = f.slab + (size_t)nz * c->F * L;
             dim3 grid((unsigned)(c->F / 256), (L + 31) / 32, nz);
-            ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
-            hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(c->dd0), c->z, sw, sb, B, (int)c->F, L, c->s2, bsplit);
+            ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, f.st);
+            hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, f.st, reinterpret_cast<const T*>(c->dd0), c->z, sw, sb, B, (int)c->F, L, c->s2, bsplit);
             LAUNCH_CHECK("decin_wgrad_kernel");
-            if (launch_reduce(sw, nz, (size_t)c->F * L, grads + c->poff[20], 0, 0, st)) return -1;
-            if (launch_reduce(sb, nz, (size_t)c->F, grads + c->poff[21], 0, 0, st)) return -1;
+            if (launch_reduce(sw, nz, (size_t)c->F * L, grads + c->poff[20], 0, 0, f.st)) return -1;
+            if (launch_reduce(sb, nz, (size_t)c->F, grads + c->poff[21], 0, 0, f.st)) return -1;
         }
         DenseArgs<T> a; memset(&a, 0, sizeof(a));
         a.A = reinterpret_cast<const T*>(c->dd0); a.coef = nullptr; a.slope = 1.f; a.C = 256;
@@ -695,7 +748,9 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         lb.gmu = g_mu; lb.glv = g_lv; lb.gz = g_z; lb.dlat = c->dlat; lb.B = B; lb.L = L; lb.kld_weight = kld_weight; lb.add_kl = add_kl;
         hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, lb);
         LAUNCH_CHECK("latent_bwd_kernel");
-        hipLaunchKernelGGL(colsum_kernel, dim3(2 * L), dim3(64), 0, st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L);
+        SideFork f = fork_side(c, st);
+        if (f.rc) return f.rc;
+        hipLaunchKernelGGL(colsum_kernel, dim3(2 * L), dim3(64), 0, f.st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L);
         LAUNCH_CHECK("colsum_kernel");
     }
     // fc_mu / fc_var backward
@@ -706,13 +761,15 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         {
             const int nz = std::max(1, std::min(8, B / 8));
             w.bsplit = (B + nz - 1) / nz;
-            float* smu = c->slab; float* svar = c->slab + (size_t)nz * L * c->F;
+            SideFork f = fork_side(c, st);   // (no new dependency: the side stream is already past latent_bwd)
+            if (f.rc) return f.rc;
+            float* smu = f.slab; float* svar = f.slab + (size_t)nz * L * c->F;
             w.dwmu = smu; w.dwvar = svar;
-            ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, st);
-            hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, st, w);
+            ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
+            hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, f.st, w);
             LAUNCH_CHECK("fc_wgrad_kernel");
-            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, st)) return -1;
-            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, st)) return -1;
+            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, f.st)) return -1;
+            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, f.st)) return -1;
         }
         FcDgradArgs<T> d;
         d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
@@ -732,7 +789,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         w.s0 = reinterpret_cast<const T*>(l.dz); w.s1 = reinterpret_cast<const T*>(l.y); w.scoef = l.block + LC_P0 * l.C; w.sslope = 1.f; w.s_two = 1;
         w.g0 = reinterpret_cast<const T*>(lp.y); w.gcoef = lp.block; w.gslope = kSlope; w.g_two = 0;
         w.B = B; w.Hs = l.H; w.Ws = l.W; w.CA = l.C; w.CB = lp.C;
-        if (launch_wgrad<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
         a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
@@ -745,11 +802,17 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
-        ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, st);
-        hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, st, x, reinterpret_cast<const T*>(c->lay[0].dz),
-                           reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, c->slab, B, H, H);
+        SideFork f = fork_side(c, st);
+        if (f.rc) return f.rc;
+        ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, f.st);
+        hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, f.st, x, reinterpret_cast<const T*>(c->lay[0].dz),
+                           reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, f.slab, B, H, H);
         LAUNCH_CHECK("conv1_wgrad_kernel");
-        if (launch_reduce(c->slab, grid, 288, grads + c->poff[0], 32, 1, st)) return -1;
+        if (launch_reduce(f.slab, grid, 288, grads + c->poff[0], 32, 1, f.st)) return -1;
+    }
+    if (c->use_side_stream) {
+        HIP_CHECK_RET(hipEventRecord(c->ev_join, c->side));
+        HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_join, 0));
     }
     return 0;
 }
