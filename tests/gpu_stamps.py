@@ -13,8 +13,9 @@ Lb = _lib.lib(); Lb.vae_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_
 for k, v in (json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}).items():
     assert Lb.vae_set_option(model._ctx.handle, k.encode(), v) == 0
 names = ["barrierA", "write_patch", "barrierB", "issue", "mfma", "epilogue"]
-for tag, epi in [("encoder.3", 0), ("encoder.1", 0), ("final_layer.0", 1), ("decoder.0", 2), ("decoder.1", 1)]:
-    buf = torch.zeros(768 * 4 * 6, dtype=torch.int64, device="cuda")
+for tag, epi in [("encoder.3", 0), ("encoder.1", 0), ("final_layer.0", 1), ("decoder.0", 2), ("decoder.1", 1),
+                 ("final_layer.0", 16), ("decoder.2", 16), ("decoder.0", 16), ("encoder.1", 17), ("encoder.3", 17)]:   # +16: up kernels
+    buf = torch.zeros(1024 * 4 * 6, dtype=torch.int64, device="cuda")
     Lb.vae_debug_stamps(model._ctx.handle, tag.encode(), epi, buf.data_ptr())
     model.fused_forward_backward(x); torch.cuda.synchronize()
     Lb.vae_debug_stamps(model._ctx.handle, b"", 0, None)

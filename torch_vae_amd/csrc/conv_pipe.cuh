@@ -13,6 +13,7 @@
 //     channel per workgroup at the very end.
 #pragma once
 #include "conv_mfma.cuh"
+#include <type_traits>
 
 struct TileGeo { int b0, y0, x0, n0; };
 
@@ -28,12 +29,14 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 // WV = wave-independent mode: every wave owns a 32-pixel M tile with its own patch / out tile in LDS and walks
 // its own sequence of tiles; no workgroup barrier inside the persistent loop (LDS traffic of one wave is
 // processed in order), so the 8 waves of a CU sit in different phases and cover each other's stalls.
-template <typename T, int NT, bool TWO_SRC, bool WV>
+// EPI is a template parameter (the per-element epilogue is straight-line code); forward launches stage one source
+// tensor with BatchNorm+LeakyReLU, backward launches (EPI_BWD / EPI_PLAIN) stage the two-source gradient operand.
+template <typename T, int NT, int EPI, bool WV>
 __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+    constexpr bool TWO_SRC = EPI != EPI_FWD;
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 10;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;   // out-tile row bytes / chunks
     constexpr int OPL = OCH / 2;                                                     // out chunks per lane (32 px per wave)
-    const int EPI = a.epi;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
@@ -224,36 +227,40 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         STAMP(4)
         if (chunk == NCH - 1) {
             if (nhave && nchunk == 0 && EPI == EPI_BWD) issue_y(nxt);
-            // ---- epilogue through the wave-private LDS tile
+            // ---- epilogue through the wave-private LDS tile.  Rows of images beyond the batch (only possible in the
+            // last batch tile) carry acc == 0: they add nothing to the backward statistics, and the forward
+            // statistics skip them through the checked variant, chosen once per tile.
+            auto epi_body = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = cur.n0 + nt * 32 + r;
-                float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f;
-                if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
-                if (EPI == EPI_BWD) {
-                    sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
-                    is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = acc_row(i, lane), RR = wv0 * 32 + row;
-                    const bool valid = (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B;
-                    T* cell = reinterpret_cast<T*>(mytile + row * OPITCH) + nt * 32 + r;
-                    if (EPI == EPI_FWD) {
-                        const float v = round_as<T>(acc[nt][i] + bv);
-                        *cell = fromfloat<T>(v);
-                        if (valid) { s1[nt] += v; s2[nt] += v * v; }
-                    } else if (EPI == EPI_BWD) {
-                        const float y = tofloat(*cell), z = y * sc + sh;
-                        const float dz = round_as<T>(z > 0.f ? acc[nt][i] : acc[nt][i] * a.oslope);
-                        *cell = fromfloat<T>(dz);
-                        if (valid) { s1[nt] += dz; s2[nt] += dz * (y * is + xm); }
-                    } else {
-                        *cell = fromfloat<T>(acc[nt][i]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = cur.n0 + nt * 32 + r;
+                    float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f;
+                    if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
+                    if constexpr (EPI == EPI_BWD) {
+                        sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
+                        is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
                     }
-                    acc[nt][i] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = acc_row(i, lane), RR = wv0 * 32 + row;
+                        T* cell = reinterpret_cast<T*>(mytile + row * OPITCH) + nt * 32 + r;
+                        if constexpr (EPI == EPI_FWD) {
+                            const float v = round_as<T>(acc[nt][i] + bv);
+                            *cell = fromfloat<T>(v);
+                            if (!decltype(checked)::value || (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B) { s1[nt] += v; s2[nt] += v * v; }
+                        } else if constexpr (EPI == EPI_BWD) {
+                            const float y = tofloat(*cell), z = y * sc + sh;
+                            const float dz = round_as<T>(z > 0.f ? acc[nt][i] : acc[nt][i] * a.oslope);
+                            *cell = fromfloat<T>(dz);
+                            s1[nt] += dz; s2[nt] += dz * (y * is + xm);
+                        } else {
+                            *cell = fromfloat<T>(acc[nt][i]);
+                        }
+                        acc[nt][i] = 0.f;
+                    }
                 }
-            }
+            };
+            if (EPI != EPI_FWD || cur.b0 + TB <= a.B) epi_body(std::false_type{}); else epi_body(std::true_type{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (wave-private rows)
 #pragma unroll
             for (int u = 0; u < OPL; ++u) {
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
 #undef STAMP
 
-    if (EPI != EPI_PLAIN) {
+    if constexpr (EPI != EPI_PLAIN) {
         // all (M tile, N tile) pairs of one workgroup may span several N tiles: statistics are kept per
         // pair's channel block only when ntiles_n == 1; otherwise flush per pair (see launcher: grid is
         // arranged so that a workgroup keeps one N tile).
@@ -291,12 +298,12 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int NT, bool TWO_SRC, bool WV>
-__global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+template <typename T, int NT, int EPI, bool WV>
+__global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)) ? 1 : 2)) void up2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+    constexpr bool TWO_SRC = EPI != EPI_FWD;
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 3;
     constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;
     constexpr int OPL = OCH;                          // 64 output pixels per wave per round (32 base px x 2 x-parities)
-    const int EPI = a.epi;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
@@ -341,21 +348,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
 
     // a thread always stages the same 16-byte quarter of a pixel (stid & 3): its per-channel coefficients live in
     // registers, reloaded only when the channel chunk changes
+    // (the backward variant keeps them in LDS: its 4 parity accumulators + two-source prefetch fill the register file)
     constexpr int NE = Vec16<T>::N;
-    float k0[NE], k1[TWO_SRC ? NE : 1], k2[NE];
+    constexpr bool KREG = !TWO_SRC;
+    float k0[KREG ? NE : 1], k2[KREG ? NE : 1];
+    int kcb = 0;
     auto load_coefs = [&](int c0) __attribute__((always_inline)) {
-        const int cb = c0 + (stid & 3) * E16;
+        kcb = c0 + (stid & 3) * E16;
+        if constexpr (KREG) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            k0[e] = cf[cb + e]; k2[e] = cf[2 * Cin + cb + e];
-            if constexpr (TWO_SRC) k1[e] = cf[Cin + cb + e];
+            for (int e = 0; e < NE; ++e) { k0[e] = cf[kcb + e]; k2[e] = cf[2 * Cin + kcb + e]; }
         }
     };
     auto xform = [&](const Vec16<T>& v0, const Vec16<T>& v1) __attribute__((always_inline)) {
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            if constexpr (TWO_SRC) o.set(e, v0.get(e) * k0[e] + v1.get(e) * k1[e] + k2[e]);
+            if constexpr (TWO_SRC) o.set(e, v0.get(e) * cf[kcb + e] + v1.get(e) * cf[Cin + kcb + e] + cf[2 * Cin + kcb + e]);
             else o.set(e, leaky(v0.get(e) * k0[e] + k2[e], a.slope));
         }
         return o;
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
             const int n = n0w + nt * 32 + r;
             ebv[nt] = (EPI == EPI_FWD && a.bias) ? a.bias[n] : 0.f;
             esc[nt] = esh[nt] = eis[nt] = exm[nt] = 0.f;
-            if (EPI == EPI_BWD) {
+            if constexpr (EPI == EPI_BWD) {
                 esc[nt] = a.ocoef[LC_SC * Cout + n]; esh[nt] = a.ocoef[LC_SH * Cout + n];
                 eis[nt] = a.ocoef[LC_INVSTD * Cout + n]; exm[nt] = a.ocoef[LC_XM * Cout + n];
             }
@@ -441,17 +450,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) issue(cur, 0);
+    long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
+#define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
     while (have) {
         if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A)
+        STAMP(0)
         if (NCH > 1) load_coefs(chunk * CK);
         write_patch(cur, chunk * CK);
+        STAMP(1)
         if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B)
+        STAMP(2)
         int npi = pi, nchunk = chunk + 1;
         TileGeo nxt = cur;
         if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
         const bool nhave = npi < n_pairs;
         if (nhave) issue(nxt, nchunk * CK);
         if (chunk == NCH - 1 && EPI == EPI_BWD) issue_y(cur, 0);   // rows of round 0, hidden behind the MFMAs
+        STAMP(3)
 
         const int c0 = chunk * CK;
 #pragma unroll
@@ -478,10 +493,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
             }
         }
 
+        STAMP(4)
         if (chunk == NCH - 1) {
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
-                if (EPI == EPI_BWD) {
+                if constexpr (EPI == EPI_BWD) {
 #pragma unroll
                     for (int u = 0; u < OPL; ++u) {
                         int loff; (void)out_chunk_addr(cur, py, lane + 64 * u, loff);
@@ -490,33 +506,35 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
                     if (py == 0) issue_y(cur, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                auto epi_body = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = ebv[nt], sc = esc[nt], sh = esh[nt], is = eis[nt], xm = exm[nt];
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float bv = ebv[nt], sc = esc[nt], sh = esh[nt], is = eis[nt], xm = exm[nt];
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
+                        for (int px = 0; px < 2; ++px) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int row = acc_row(i, lane), RR = wv0 * 32 + row;
-                            const bool valid = (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B;
-                            T* cell = reinterpret_cast<T*>(mytile + (2 * row + px) * OPITCH) + nt * 32 + r;
-                            const float av = acc[py * 2 + px][nt][i];
-                            if (EPI == EPI_FWD) {
-                                const float v = round_as<T>(av + bv);
-                                *cell = fromfloat<T>(v);
-                                if (valid) { s1[nt] += v; s2[nt] += v * v; }
-                            } else if (EPI == EPI_BWD) {
-                                const float y = tofloat(*cell), z = y * sc + sh;
-                                const float dz = round_as<T>(z > 0.f ? av : av * a.oslope);
-                                *cell = fromfloat<T>(dz);
-                                if (valid) { s1[nt] += dz; s2[nt] += dz * (y * is + xm); }
-                            } else {
-                                *cell = fromfloat<T>(av);
+                            for (int i = 0; i < 16; ++i) {
+                                const int row = acc_row(i, lane), RR = wv0 * 32 + row;
+                                T* cell = reinterpret_cast<T*>(mytile + (2 * row + px) * OPITCH) + nt * 32 + r;
+                                const float av = acc[py * 2 + px][nt][i];
+                                if constexpr (EPI == EPI_FWD) {
+                                    const float v = round_as<T>(av + bv);
+                                    *cell = fromfloat<T>(v);
+                                    if (!decltype(checked)::value || (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B) { s1[nt] += v; s2[nt] += v * v; }
+                                } else if constexpr (EPI == EPI_BWD) {
+                                    const float y = tofloat(*cell), z = y * sc + sh;
+                                    const float dz = round_as<T>(z > 0.f ? av : av * a.oslope);
+                                    *cell = fromfloat<T>(dz);
+                                    s1[nt] += dz; s2[nt] += dz * (y * is + xm);   // rows beyond the batch carry av == 0
+                                } else {
+                                    *cell = fromfloat<T>(av);
+                                }
+                                acc[py * 2 + px][nt][i] = 0.f;
                             }
-                            acc[py * 2 + px][nt][i] = 0.f;
                         }
                     }
-                }
+                };
+                if (EPI != EPI_FWD || cur.b0 + TB <= a.B) epi_body(std::false_type{}); else epi_body(std::true_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < OPL; ++u) {
@@ -527,10 +545,13 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void up2_kernel(ConvArgs<T> 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before round 1 overwrites the tile
             }
         }
+        STAMP(5)
         pi = npi; chunk = nchunk; cur = nxt; have = nhave;
     }
+    if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
+#undef STAMP
 
-    if (EPI != EPI_PLAIN) {
+    if constexpr (EPI != EPI_PLAIN) {
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

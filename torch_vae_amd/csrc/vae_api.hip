@@ -303,7 +303,7 @@ template <typename T>
 static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st) {
     // register budget: two-source (gradient) loads and the 4-parity accumulators of `up` keep NT at 1
     int NT = std::min(c->knob_nt_max, a.Cout / 32);
-    NT = NT >= 8 ? 8 : (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1));
+    NT = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
     if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     // wave-independent tiles (32 pixels per wave, no workgroup barrier in the loop) vs one 128-pixel tile per workgroup
@@ -321,7 +321,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
                        (size_t)TB * PHW * 4 * 8;   // + the per-item staging table
     if (lds > 160 * 1024) return vae_set_error("conv_pipe", "tile does not fit LDS");
     if (c->knob_ablate_b) a.two_src |= 2;
-    a.dbg = (c->dbg_buf && is_down && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == c->dbg_epi) ? c->dbg_buf : nullptr;
+    a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
     if ((a.two_src & 1) && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
     const int n_wg_pairs = wv ? ((n_mt + 3) / 4) * ntn : n_pairs;    // workgroup-level work items
@@ -332,12 +332,15 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
                  sizeof(T) * (px_in * a.Cin * ((a.two_src & 1) ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
                  2.0 * 9 * a.Cin * a.Cout * px_lo, st);
-#define PIPE_CASE(K, N, W, V) { if (set_lds(K<T, N, W, V>, lds)) return -1; hipLaunchKernelGGL((K<T, N, W, V>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
-#define PIPE_WV(K, N, W) { if (wv) PIPE_CASE(K, N, W, true) else PIPE_CASE(K, N, W, false) }
-#define PIPE_SRC(K, N) { if (a.two_src & 1) PIPE_WV(K, N, true) else PIPE_WV(K, N, false) }
-    if (is_down) { if (NT == 1) PIPE_SRC(down2_kernel, 1) else if (NT == 2) PIPE_SRC(down2_kernel, 2) else if (NT == 4) PIPE_SRC(down2_kernel, 4) else PIPE_SRC(down2_kernel, 8) }
-    else { if (NT == 1) PIPE_SRC(up2_kernel, 1) else PIPE_SRC(up2_kernel, 2) }
-#undef PIPE_SRC
+    if (((a.two_src & 1) != 0) != (a.epi != EPI_FWD)) return vae_set_error("conv_pipe", "forward launches stage one source, backward launches two");
+#define PIPE_CASE(K, N, E, V) { if (set_lds(K<T, N, E, V>, lds)) return -1; hipLaunchKernelGGL((K<T, N, E, V>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
+#define PIPE_WV(K, N, E) { if constexpr (sizeof(T) == 2) { if (wv) PIPE_CASE(K, N, E, true) else PIPE_CASE(K, N, E, false) } else PIPE_CASE(K, N, E, false) }
+#define PIPE_EPI(K, N) { if (a.epi == EPI_FWD) PIPE_WV(K, N, EPI_FWD) else if (a.epi == EPI_BWD) PIPE_WV(K, N, EPI_BWD) else PIPE_WV(K, N, EPI_PLAIN) }
+    if (is_down) { if (NT == 1) PIPE_EPI(down2_kernel, 1) else if (NT == 2) PIPE_EPI(down2_kernel, 2) else PIPE_EPI(down2_kernel, 4) }
+    else if (a.epi == EPI_FWD) { if (NT == 1) PIPE_WV(up2_kernel, 1, EPI_FWD) else PIPE_WV(up2_kernel, 2, EPI_FWD) }
+    else if (a.epi == EPI_BWD) PIPE_WV(up2_kernel, 1, EPI_BWD)
+    else return vae_set_error("conv_pipe", "up kernel has no plain epilogue");
+#undef PIPE_EPI
 #undef PIPE_WV
 #undef PIPE_CASE
     LAUNCH_CHECK("conv_pipe_kernel");
