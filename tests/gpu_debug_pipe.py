@@ -1,0 +1,33 @@
+"""Diagnostic (GPU box): pipelined vs one-tile-per-workgroup conv kernels, tensor by tensor."""
+import sys, os
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import vae_oracle as vo
+from torch_vae_amd import _lib
+from util import make_model, perturbed_params
+H, L, B, gen, dtype = 64, 16, 5, True, "bf16"
+p = perturbed_params(L, H, 8, gen)
+x = torch.from_numpy(vo.synth_pianoroll(B, H, 12)).cuda()
+eps = torch.from_numpy(vo.counter_normal(B * L, 12, 5).reshape(B, L)).float().cuda()
+res = []
+for use in (0, 1):
+    model = make_model(H, L, gen, dtype, p)
+    model._context(B)
+    assert _lib.lib().vae_set_option(model._ctx.handle, b"use_pipelined", use) == 0
+    out3, xhat = model.fused_forward_backward(x, eps=eps)
+    torch.cuda.synchronize()
+    t = {}
+    C = [32, 64, 128, 256, 128, 64, 32, 32]; S = [32, 16, 8, 4, 8, 16, 32, 64]
+    for i in range(16):
+        n = B * C[i & 7] * S[i & 7] ** 2
+        out = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(model._ctx.handle, i, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        t[i] = out.cpu().numpy()
+    t["xhat"] = xhat.cpu().numpy().ravel()
+    res.append(t)
+for k in res[0]:
+    a, b = res[0][k], res[1][k]
+    nd = int((a != b).sum())
+    print(k, "n", a.size, "differ", nd, "max abs", float(np.abs(a - b).max()), "rel_l2", float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30))))

@@ -327,12 +327,15 @@ def test_pipelined_and_simple_conv_kernels_agree():
             assert _lib.lib().vae_set_option(model._ctx.handle, b"use_pipelined", use) == 0
             out3, xhat = model.fused_forward_backward(x, eps=eps)
             res.append((out3.tolist(), xhat.clone(), flat_grad_dict(model)))
-        np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5)
-        assert rel_l2(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-5
+        # The two kernel families add the conv bias at different points of the f32 accumulation chain, so in bf16
+        # mode a few stored activations round the other way and the flips cascade: bf16-level agreement there,
+        # f32-level agreement in f32 mode.
+        np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5 if dtype == "f32" else 2e-4)
+        assert rel_l2(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < (1e-5 if dtype == "f32" else 2e-3)
         for n in res[0][2]:
             if n in PRE_BN_BIAS:
                 continue
-            tol = 5e-3 if dtype == "f32" else 2e-2   # statistics are summed in a different order: kink ties / bf16 rounding ties may flip
+            tol = 5e-3 if dtype == "f32" else 4e-2   # statistics are summed in a different order: kink ties / bf16 rounding ties may flip
             assert rel_l2(res[1][2][n], res[0][2][n]) < tol, (H, dtype, n)
 
 

@@ -115,6 +115,65 @@ __device__ __forceinline__ double wave_sum(double v) {
 //  0 sc   1 zero  2 sh   3 invstd  4 xm(=-mean*invstd)  5 p0  6 p1  7 p2  8 mean  9 var
 enum { LC_SC = 0, LC_ZERO = 1, LC_SH = 2, LC_INVSTD = 3, LC_XM = 4, LC_P0 = 5, LC_P1 = 6, LC_P2 = 7, LC_MEAN = 8, LC_VAR = 9, LC_ROWS = 10 };
 
+// ---- BatchNorm finalisation folded into the consumer kernel ------------------------------------------------
+// A train-mode BatchNorm layer is "finalised" (batch statistics -> per-channel staging coefficients) by whichever
+// kernel stages its tensor next: every workgroup derives the coefficients of the channels it needs in its
+// prologue (a few f64 operations per channel), and one designated workgroup also writes the layer's coefficient
+// block, running statistics (forward) or dgamma/dbeta (backward).  This removes one dependent launch per layer
+// boundary.  Forward (models.py:46,69,78 of the reference: BatchNorm2d, momentum 0.1, unbiased running variance):
+//   sc = gamma*invstd, sh = beta - mean*sc.   Backward: dL/dy = dz*p0 + y*p1 + p2 with p0 = gamma*invstd,
+//   p1 = -p0*invstd*mean(dz*xhat), p2 = -p0*mean(dz) + p0*mean(dz*xhat)*mean*invstd.
+struct BnFuse {
+    const double* stat;             // forward: [sum y | sum y^2]; backward: [sum dz | sum dz*xhat]   (2*C)
+    const float* gamma; const float* beta;
+    float* block;                   // LC_* rows, stride C
+    float* running_mean; float* running_var; long long* nbt;
+    float* dgamma; float* dbeta; float* dconv_bias;
+    double count; float eps, momentum;
+    int C, mode, update_running;    // mode 0: coefficients are read from the block; 1: forward; 2: backward
+};
+enum { BNF_NONE = 0, BNF_FWD = 1, BNF_BWD = 2 };
+
+__device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool writer, float& k0, float& k1, float& k2) {
+    const int C = f.C;
+    if (f.mode == BNF_FWD) {
+        const double mean = f.stat[c] / f.count;
+        double var = f.stat[C + c] / f.count - mean * mean;
+        if (var < 0) var = 0;
+        const double invstd = 1.0 / sqrt(var + (double)f.eps);
+        const double sc = (double)f.gamma[c] * invstd;
+        k0 = (float)sc; k1 = 0.f; k2 = (float)((double)f.beta[c] - mean * sc);
+        if (writer) {
+            f.block[LC_SC * C + c] = k0; f.block[LC_ZERO * C + c] = 0.f; f.block[LC_SH * C + c] = k2;
+            f.block[LC_INVSTD * C + c] = (float)invstd; f.block[LC_XM * C + c] = (float)(-mean * invstd);
+            f.block[LC_MEAN * C + c] = (float)mean; f.block[LC_VAR * C + c] = (float)var;
+            if (f.update_running) {
+                const double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+                f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
+                f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unb);
+                if (c == 0 && f.nbt) f.nbt[0] += 1;
+            }
+        }
+    } else {
+        const double sdz = f.stat[c], sdzx = f.stat[C + c];
+        const double invstd = f.block[LC_INVSTD * C + c], mean = f.block[LC_MEAN * C + c];
+        const double s = (double)f.gamma[c] * invstd, m1 = sdz / f.count, m2 = sdzx / f.count;
+        k0 = (float)s; k1 = (float)(-s * m2 * invstd); k2 = (float)(-s * m1 + s * m2 * mean * invstd);
+        if (writer) {
+            f.block[LC_P0 * C + c] = k0; f.block[LC_P1 * C + c] = k1; f.block[LC_P2 * C + c] = k2;
+            f.dgamma[c] = (float)sdzx; f.dbeta[c] = (float)sdz;
+            if (f.dconv_bias) f.dconv_bias[c] = 0.f;
+        }
+    }
+}
+// standalone finalisation (consumers without the fused prologue, e.g. the one-tile-per-workgroup kernels)
+__global__ void bn_finalize_kernel(BnFuse f) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= f.C) return;
+    float k0, k1, k2;
+    bn_fused_channel(f, c, true, k0, k1, k2);
+}
+
 #define HIP_CHECK_RET(expr)                                                       \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

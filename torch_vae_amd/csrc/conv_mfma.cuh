@@ -35,6 +35,7 @@ template <typename T> struct ConvArgs {
     int two_src, epi;                                              // runtime: gradient-operand load / epilogue kind
     unsigned m_pp, m_pw, m_tx, m_txy;                              // fastdiv magics: PP, PW, tiles_x, tiles_x*tiles_y
     long long* dbg;                                                // diagnostic builds only: per-wave phase cycle counters
+    BnFuse fuse;                                                   // mode != 0: derive the staging coefficients from batch statistics (pipelined kernels)
 };
 
 // x / d for small x via one mul_hi: m = ceil(2^32 / d), exact for x, d < 2^16
@@ -344,6 +345,7 @@ template <typename T> struct WgradArgs {
     int lth, ltw, lTB, tiles_x, tiles_y, n_tiles, tiles_per_split;
     int use_tr16;
     unsigned m_pp, m_pw, m_tx, m_txy;
+    BnFuse fuse;                                                 // mode == BNF_BWD: the gradient operand's coefficients come from batch statistics
 };
 
 static constexpr int WG_KP = 64;  // low-res pixels per K tile
@@ -394,8 +396,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
         }
     }
 
-    for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
-    for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
+    // staging coefficients (tile-local rows); the gradient operand's may be derived here from the batch statistics
+    if (a.fuse.mode == BNF_BWD && a.s_two) {
+        for (int i = tid; i < 32 * WA; i += 256) bn_fused_channel(a.fuse, a0 + i, false, cfs[i], cfs[32 * WA + i], cfs[2 * 32 * WA + i]);
+    } else {
+        for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
+    }
+    if (a.fuse.mode == BNF_BWD && a.g_two) {
+        for (int i = tid; i < 32 * WB; i += 256) bn_fused_channel(a.fuse, bc0 + i, false, cfg[i], cfg[32 * WB + i], cfg[2 * 32 * WB + i]);
+    } else {
+        for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
+    }
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -609,6 +620,7 @@ struct ConvOutFwdMfmaArgs {
     const bf16* yf; const float* coef; const float* wt; const float* bias; const float* target;
     float* xhat; float* dlogit; double* accum;
     int B, H, W, n_tiles; float inv_n, slope;
+    BnFuse fuse;
 };
 
 __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfmaArgs a) {
@@ -619,7 +631,10 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
     __shared__ float wred[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    if (tid < 32) { cf[tid] = a.coef[tid]; cf[32 + tid] = a.coef[64 + tid]; }
+    if (tid < 32) {
+        if (a.fuse.mode == BNF_FWD) { float k1; bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], k1, cf[32 + tid]); }
+        else { cf[tid] = a.coef[tid]; cf[32 + tid] = a.coef[64 + tid]; }
+    }
     // rows NP..NPAD of the patch image stay zero
     for (int i = tid; i < (NPAD - NP) * PITCH / 16; i += 256) *reinterpret_cast<f32x4*>(atile + NP * PITCH + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     // B operand: B[k = channel][col = tap r]
@@ -867,6 +882,7 @@ template <typename T> struct DenseArgs {
     const T* Bp;                                        // packed [K/8][Npad][8]
     float* slab;                                        // [nsplit][M][Npad]
     int M, K, Npad, ksteps_per_split;
+    BnFuse fuse;                                        // mode == BNF_FWD: coefficients derived from batch statistics (C <= 256)
 };
 
 template <typename T, int NT>
@@ -874,6 +890,15 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs<T> a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * 128 + wave * 32 + r, n0 = blockIdx.z * 32 * NT;
     const int ks0 = blockIdx.y * a.ksteps_per_split, ks1 = min(a.K / 16, ks0 + a.ksteps_per_split);
+    __shared__ float dcf[2 * 256];   // scale | shift per channel
+    if (a.coef) {
+        const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+        for (int c = tid; c < a.C; c += 256) {
+            if (a.fuse.mode == BNF_FWD) { float k1; bn_fused_channel(a.fuse, c, writer, dcf[c], k1, dcf[256 + c]); }
+            else { dcf[c] = a.coef[c]; dcf[256 + c] = a.coef[2 * a.C + c]; }
+        }
+        __syncthreads();
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -890,7 +915,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs<T> a) {
                     const int c = (k + j) & (a.C - 1);
                     float v;
                     if constexpr (sizeof(T) == 4) v = raw.v[j]; else v = (float)raw.v[j];
-                    af.set(j, leaky(v * a.coef[c] + a.coef[2 * a.C + c], a.slope));
+                    af.set(j, leaky(v * dcf[c] + dcf[256 + c], a.slope));
                 }
             } else {
                 af = raw;

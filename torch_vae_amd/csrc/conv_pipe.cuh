@@ -17,6 +17,39 @@
 
 struct TileGeo { int b0, y0, x0, n0; };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// round a pair the way it is stored (one packed conversion for bf16) and return the stored values as f32
+template <typename T> __device__ __forceinline__ f32x2 round_pair(f32x2 v, T& o0, T& o1);
+template <> __device__ __forceinline__ f32x2 round_pair<float>(f32x2 v, float& o0, float& o1) { o0 = v.x; o1 = v.y; return v; }
+template <> __device__ __forceinline__ f32x2 round_pair<bf16>(f32x2 v, bf16& o0, bf16& o1) {
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    o0 = b.x; o1 = b.y;
+    return __builtin_convertvector(b, f32x2);
+}
+// Epilogue of one accumulator pair (two pixels of one channel) against its two LDS cells; statistics are
+// accumulated as packed pairs (v_pk_add_f32 / v_pk_fma_f32).  Backward: s2 collects sum dz*y; the caller
+// finishes sum dz*xhat = invstd * s2 + xm * s1.
+template <typename T, int EPI, bool CHECKED>
+__device__ __forceinline__ void epi_pair(float a0, float a1, T* c0, T* c1, bool ok0, bool ok1, float sc, float sh, float oslope,
+                                         f32x2& s1, f32x2& s2) {
+    f32x2 av = {a0, a1};
+    if constexpr (EPI == EPI_FWD) {
+        f32x2 v = round_pair<T>(av, *c0, *c1);
+        if constexpr (CHECKED) { v.x = ok0 ? v.x : 0.f; v.y = ok1 ? v.y : 0.f; }
+        s1 += v; s2 += v * v;
+    } else if constexpr (EPI == EPI_BWD) {
+        const f32x2 y = {tofloat(*c0), tofloat(*c1)};
+        const f32x2 z = y * sc + sh;
+        f32x2 g = av;
+        g.x = z.x > 0.f ? g.x : g.x * oslope; g.y = z.y > 0.f ? g.y : g.y * oslope;
+        const f32x2 dz = round_pair<T>(g, *c0, *c1);
+        s1 += dz; s2 += dz * y;
+    } else {
+        (void)round_pair<T>(av, *c0, *c1);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int ntiles_n, int nch_out) {
     const int mt = pi / ntiles_n, nt = pi - mt * ntiles_n;
@@ -59,18 +92,38 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                              ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15));
     }
 
-    for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
+        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    }
 
     const int R = wv0 * 32 + r;
     const int pbase = ((R >> (a.lth + a.ltw)) * PH + 2 * ((R >> a.ltw) & (th - 1))) * PW + 2 * (R & (tw - 1));
 
+    // one N tile per workgroup for its whole life: epilogue coefficients live in registers; the forward
+    // accumulators start from the conv bias
+    float ebv[NT], esc[NT], esh[NT], eis[NT], exm[NT];
+    {
+        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0w + nt * 32 + r;
+            ebv[nt] = (EPI == EPI_FWD && a.bias) ? a.bias[n] : 0.f;
+            esc[nt] = esh[nt] = eis[nt] = exm[nt] = 0.f;
+            if constexpr (EPI == EPI_BWD) {
+                esc[nt] = a.ocoef[LC_SC * Cout + n]; esh[nt] = a.ocoef[LC_SH * Cout + n];
+                eis[nt] = a.ocoef[LC_INVSTD * Cout + n]; exm[nt] = a.ocoef[LC_XM * Cout + n];
+            }
+        }
+    }
     f32x16 acc[NT];
-    float s1[NT], s2[NT];
+    f32x2 s1[NT], s2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        s1[nt] = 0.f; s2[nt] = 0.f;
+        s1[nt] = f32x2{0.f, 0.f}; s2[nt] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[nt][i] = ebv[nt];
     }
 
     // a thread always stages the same 16-byte quarter of a pixel (stid & 3): its per-channel coefficients live in
@@ -139,19 +192,26 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
         }
     };
-    // global element offset of out-tile chunk (wave-local chunk id) or -1
-    auto out_chunk_addr = [&](const TileGeo& g, int id, int& loff) __attribute__((always_inline)) -> long {
-        const int row = id / OCH, qq = id - row * OCH, RR = wv0 * 32 + row;
-        loff = row * OPITCH + qq * 16;
-        const int b = g.b0 + (RR >> (a.lth + a.ltw));
-        if (b >= a.B) return -1;
-        const int oy = g.y0 + ((RR >> a.ltw) & (th - 1)), ox = g.x0 + (RR & (tw - 1));
-        return ((((long)b * a.Hs + oy) * a.Ws + ox) * Cout + g.n0 + qq * E16);
+    // out-tile chunk u of this lane (wave-local chunk id = lane + 64u): the tile-independent part of its address is
+    // computed once: orel = element offset relative to the tile origin, opk = LDS offset | image-in-tile << 20
+    int orel[OPL], opk[OPL];
+#pragma unroll
+    for (int u = 0; u < OPL; ++u) {
+        const int id = lane + 64 * u, row = id / OCH, qq = id - row * OCH, RR = wv0 * 32 + row;
+        const int img = RR >> (a.lth + a.ltw), ty = (RR >> a.ltw) & (th - 1), tx = RR & (tw - 1);
+        orel[u] = ((img * a.Hs + ty) * a.Ws + tx) * Cout + qq * E16;
+        opk[u] = (row * OPITCH + qq * 16) | (img << 20);
+    }
+    // global element offset of out-tile chunk u, or -1 (image beyond the batch)
+    auto out_chunk_addr = [&](const TileGeo& g, int u, int& loff) __attribute__((always_inline)) -> int {
+        loff = opk[u] & 0xfffff;
+        const int base = ((g.b0 * a.Hs + g.y0) * a.Ws + g.x0) * Cout + g.n0;
+        return (g.b0 + (opk[u] >> 20)) < a.B ? base + orel[u] : -1;
     };
     auto issue_y = [&](const TileGeo& g) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
-            int loff; long gi = out_chunk_addr(g, lane + 64 * u, loff);
+            int loff; const int gi = out_chunk_addr(g, u, loff);
             prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
         }
     };
@@ -174,7 +234,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         if (EPI == EPI_BWD && chunk == 0) {
 #pragma unroll
             for (int u = 0; u < OPL; ++u) {
-                int loff; (void)out_chunk_addr(cur, lane + 64 * u, loff);
+                int loff; (void)out_chunk_addr(cur, u, loff);
                 *reinterpret_cast<decltype(Vec16<T>::v)*>(mytile + loff) = prey[u];
             }
         }
@@ -233,30 +293,16 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             auto epi_body = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = cur.n0 + nt * 32 + r;
-                    float bv = 0.f, sc = 0.f, sh = 0.f, is = 0.f, xm = 0.f;
-                    if (EPI == EPI_FWD) bv = a.bias ? a.bias[n] : 0.f;
-                    if constexpr (EPI == EPI_BWD) {
-                        sc = a.ocoef[LC_SC * Cout + n]; sh = a.ocoef[LC_SH * Cout + n];
-                        is = a.ocoef[LC_INVSTD * Cout + n]; xm = a.ocoef[LC_XM * Cout + n];
-                    }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = acc_row(i, lane), RR = wv0 * 32 + row;
-                        T* cell = reinterpret_cast<T*>(mytile + row * OPITCH) + nt * 32 + r;
-                        if constexpr (EPI == EPI_FWD) {
-                            const float v = round_as<T>(acc[nt][i] + bv);
-                            *cell = fromfloat<T>(v);
-                            if (!decltype(checked)::value || (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B) { s1[nt] += v; s2[nt] += v * v; }
-                        } else if constexpr (EPI == EPI_BWD) {
-                            const float y = tofloat(*cell), z = y * sc + sh;
-                            const float dz = round_as<T>(z > 0.f ? acc[nt][i] : acc[nt][i] * a.oslope);
-                            *cell = fromfloat<T>(dz);
-                            s1[nt] += dz; s2[nt] += dz * (y * is + xm);
-                        } else {
-                            *cell = fromfloat<T>(acc[nt][i]);
-                        }
-                        acc[nt][i] = 0.f;
+                    for (int i = 0; i < 16; i += 2) {
+                        const int row0 = acc_row(i, lane), row1 = acc_row(i + 1, lane);
+                        T* c0 = reinterpret_cast<T*>(mytile + row0 * OPITCH) + nt * 32 + r;
+                        T* c1 = reinterpret_cast<T*>(mytile + row1 * OPITCH) + nt * 32 + r;
+                        constexpr bool CK_ = decltype(checked)::value;
+                        const bool ok0 = !CK_ || (cur.b0 + ((wv0 * 32 + row0) >> (a.lth + a.ltw))) < a.B;
+                        const bool ok1 = !CK_ || (cur.b0 + ((wv0 * 32 + row1) >> (a.lth + a.ltw))) < a.B;
+                        epi_pair<T, EPI, CK_>(acc[nt][i], acc[nt][i + 1], c0, c1, ok0, ok1, esc[nt], esh[nt], a.oslope, s1[nt], s2[nt]);
+                        acc[nt][i] = ebv[nt]; acc[nt][i + 1] = ebv[nt];
                     }
                 }
             };
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (wave-private rows)
 #pragma unroll
             for (int u = 0; u < OPL; ++u) {
-                int loff; const long gi = out_chunk_addr(cur, lane + 64 * u, loff);
+                int loff; const int gi = out_chunk_addr(cur, u, loff);
                 const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mytile + loff);
                 if (gi >= 0) *reinterpret_cast<Vec16<T>*>(a.out + gi) = v;
             }
@@ -282,7 +328,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float v1 = s1[nt] + __shfl_xor(s1[nt], 32, 64), v2 = s2[nt] + __shfl_xor(s2[nt], 32, 64);
+            float v1 = s1[nt].x + s1[nt].y, v2 = s2[nt].x + s2[nt].y;
+            if constexpr (EPI == EPI_BWD) v2 = eis[nt] * v2 + exm[nt] * v1;   // sum dz*xhat from sum dz*y and sum dz
+            v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
             if (h == 0) { red[((wave * NT + nt) * 32 + r) * 2] = v1; red[((wave * NT + nt) * 32 + r) * 2 + 1] = v2; }
         }
         __syncthreads();
@@ -326,20 +374,24 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                              ((pix * PATCH_PITCH + q * 16) >> 4) | (py << 13) | (px << 19) | (img << 25));
     }
 
-    for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
+        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    }
 
     const int R = wv0 * 32 + r;
     const int pbase = ((R >> (a.lth + a.ltw)) * PH + ((R >> a.ltw) & (th - 1))) * PW + (R & (tw - 1));
 
     f32x16 acc[4][NT];
-    float s1[NT], s2[NT];
+    f32x2 s1[NT], s2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        s1[nt] = 0.f; s2[nt] = 0.f;
+        s1[nt] = f32x2{0.f, 0.f}; s2[nt] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[c][nt][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[c][nt][i] = 0.f;   // (re-initialised with the conv bias below)
     }
     constexpr int NTAP = 9;
     constexpr int tap_cls[NTAP] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
@@ -410,19 +462,25 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
         }
     };
-    // round py: wave-local out pixel o = 2*row + px (row = base pixel 0..31) -> LDS row o, global (2i+py, 2j+px)
-    auto out_chunk_addr = [&](const TileGeo& g, int py, int id, int& loff) __attribute__((always_inline)) -> long {
-        const int o = id / OCH, qq = id - o * OCH, row = o >> 1, px = o & 1, RR = wv0 * 32 + row;
-        loff = o * OPITCH + qq * 16;
-        const int b = g.b0 + (RR >> (a.lth + a.ltw));
-        if (b >= a.B) return -1;
-        const int oy = 2 * (g.y0 + ((RR >> a.ltw) & (th - 1))) + py, ox = 2 * (g.x0 + (RR & (tw - 1))) + px;
-        return ((((long)b * 2 * Hs + oy) * 2 * Ws + ox) * Cout + g.n0 + qq * E16);
+    // round py: wave-local out pixel o = 2*row + px (row = base pixel 0..31) -> LDS row o, global (2i+py, 2j+px).
+    // The tile-independent part of each lane's chunk addresses is computed once (orel, opk as in down2_kernel).
+    int orel[OPL], opk[OPL];
+#pragma unroll
+    for (int u = 0; u < OPL; ++u) {
+        const int id = lane + 64 * u, o = id / OCH, qq = id - o * OCH, row = o >> 1, px = o & 1, RR = wv0 * 32 + row;
+        const int img = RR >> (a.lth + a.ltw), ty = (RR >> a.ltw) & (th - 1), tx = RR & (tw - 1);
+        orel[u] = ((img * 2 * Hs + 2 * ty) * 2 * Ws + 2 * tx + px) * Cout + qq * E16;
+        opk[u] = (o * OPITCH + qq * 16) | (img << 20);
+    }
+    auto out_chunk_addr = [&](const TileGeo& g, int py, int u, int& loff) __attribute__((always_inline)) -> int {
+        loff = opk[u] & 0xfffff;
+        const int base = ((g.b0 * 2 * Hs + 2 * g.y0 + py) * 2 * Ws + 2 * g.x0) * Cout + g.n0;
+        return (g.b0 + (opk[u] >> 20)) < a.B ? base + orel[u] : -1;
     };
     auto issue_y = [&](const TileGeo& g, int py) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
-            int loff; long gi = out_chunk_addr(g, py, lane + 64 * u, loff);
+            int loff; const int gi = out_chunk_addr(g, py, u, loff);
             prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
         }
     };
@@ -440,6 +498,10 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 esc[nt] = a.ocoef[LC_SC * Cout + n]; esh[nt] = a.ocoef[LC_SH * Cout + n];
                 eis[nt] = a.ocoef[LC_INVSTD * Cout + n]; exm[nt] = a.ocoef[LC_XM * Cout + n];
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[c][nt][i] = ebv[nt];   // forward accumulators start from the conv bias
         }
     }
     // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
@@ -500,7 +562,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 if constexpr (EPI == EPI_BWD) {
 #pragma unroll
                     for (int u = 0; u < OPL; ++u) {
-                        int loff; (void)out_chunk_addr(cur, py, lane + 64 * u, loff);
+                        int loff; (void)out_chunk_addr(cur, py, u, loff);
                         *reinterpret_cast<decltype(Vec16<T>::v)*>(mytile + loff) = prey[u];
                     }
                     if (py == 0) issue_y(cur, 1);
@@ -509,27 +571,19 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 auto epi_body = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const float bv = ebv[nt], sc = esc[nt], sh = esh[nt], is = eis[nt], xm = exm[nt];
 #pragma unroll
                         for (int px = 0; px < 2; ++px) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int row = acc_row(i, lane), RR = wv0 * 32 + row;
-                                T* cell = reinterpret_cast<T*>(mytile + (2 * row + px) * OPITCH) + nt * 32 + r;
-                                const float av = acc[py * 2 + px][nt][i];
-                                if constexpr (EPI == EPI_FWD) {
-                                    const float v = round_as<T>(av + bv);
-                                    *cell = fromfloat<T>(v);
-                                    if (!decltype(checked)::value || (cur.b0 + (RR >> (a.lth + a.ltw))) < a.B) { s1[nt] += v; s2[nt] += v * v; }
-                                } else if constexpr (EPI == EPI_BWD) {
-                                    const float y = tofloat(*cell), z = y * sc + sh;
-                                    const float dz = round_as<T>(z > 0.f ? av : av * a.oslope);
-                                    *cell = fromfloat<T>(dz);
-                                    s1[nt] += dz; s2[nt] += dz * (y * is + xm);   // rows beyond the batch carry av == 0
-                                } else {
-                                    *cell = fromfloat<T>(av);
-                                }
-                                acc[py * 2 + px][nt][i] = 0.f;
+                            for (int i = 0; i < 16; i += 2) {
+                                const int row0 = acc_row(i, lane), row1 = acc_row(i + 1, lane);
+                                T* c0 = reinterpret_cast<T*>(mytile + (2 * row0 + px) * OPITCH) + nt * 32 + r;
+                                T* c1 = reinterpret_cast<T*>(mytile + (2 * row1 + px) * OPITCH) + nt * 32 + r;
+                                constexpr bool CK_ = decltype(checked)::value;
+                                const bool ok0 = !CK_ || (cur.b0 + ((wv0 * 32 + row0) >> (a.lth + a.ltw))) < a.B;
+                                const bool ok1 = !CK_ || (cur.b0 + ((wv0 * 32 + row1) >> (a.lth + a.ltw))) < a.B;
+                                epi_pair<T, EPI, CK_>(acc[py * 2 + px][nt][i], acc[py * 2 + px][nt][i + 1], c0, c1, ok0, ok1, esc[nt], esh[nt],
+                                                      a.oslope, s1[nt], s2[nt]);
+                                acc[py * 2 + px][nt][i] = ebv[nt]; acc[py * 2 + px][nt][i + 1] = ebv[nt];
                             }
                         }
                     }
@@ -538,7 +592,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < OPL; ++u) {
-                    int loff; const long gi = out_chunk_addr(cur, py, lane + 64 * u, loff);
+                    int loff; const int gi = out_chunk_addr(cur, py, u, loff);
                     const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mytile + loff);
                     if (gi >= 0) *reinterpret_cast<Vec16<T>*>(a.out + gi) = v;
                 }
@@ -555,7 +609,9 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float v1 = s1[nt] + __shfl_xor(s1[nt], 32, 64), v2 = s2[nt] + __shfl_xor(s2[nt], 32, 64);
+            float v1 = s1[nt].x + s1[nt].y, v2 = s2[nt].x + s2[nt].y;
+            if constexpr (EPI == EPI_BWD) v2 = eis[nt] * v2 + exm[nt] * v1;   // sum dz*xhat from sum dz*y and sum dz
+            v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
             if (h == 0) { red[((wave * NT + nt) * 32 + r) * 2] = v1; red[((wave * NT + nt) * 32 + r) * 2 + 1] = v2; }
         }
         __syncthreads();

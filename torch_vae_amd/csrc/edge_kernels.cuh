@@ -321,35 +321,7 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// BatchNorm2d train-mode finalisation (models.py:46,69,78): batch statistics ->
-// load-transform coefficients; running stats with momentum 0.1 and unbiased variance.
-struct BnFwdArgs {
-    const double* stat; const float* gamma; const float* beta; float* block;  // block rows LC_*, stride C
-    float* running_mean; float* running_var; long long* nbt;
-    int C; double count; float eps, momentum; int update_running;
-};
-__global__ void bn_fwd_finalize_kernel(BnFwdArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && a.update_running && a.nbt) a.nbt[0] += 1;
-    if (c >= a.C) return;
-    const double mean = a.stat[c] / a.count;
-    double var = a.stat[a.C + c] / a.count - mean * mean;
-    if (var < 0) var = 0;
-    const double invstd = 1.0 / sqrt(var + (double)a.eps);
-    const double sc = (double)a.gamma[c] * invstd;
-    a.block[LC_SC * a.C + c] = (float)sc;
-    a.block[LC_ZERO * a.C + c] = 0.f;
-    a.block[LC_SH * a.C + c] = (float)((double)a.beta[c] - mean * sc);
-    a.block[LC_INVSTD * a.C + c] = (float)invstd;
-    a.block[LC_XM * a.C + c] = (float)(-mean * invstd);
-    a.block[LC_MEAN * a.C + c] = (float)mean;
-    a.block[LC_VAR * a.C + c] = (float)var;
-    if (a.update_running) {
-        const double unb = a.count > 1 ? var * a.count / (a.count - 1) : var;
-        a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mean);
-        a.running_var[c] = (float)((1.0 - a.momentum) * a.running_var[c] + a.momentum * unb);
-    }
-}
+// BatchNorm: train-mode finalisation lives in common.cuh (BnFuse, folded into the consumer kernels).
 // eval-mode coefficients from running statistics (evaluation path / model.eval())
 __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float* block, int C, float eps) {
@@ -362,25 +334,6 @@ __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const
     block[LC_INVSTD * C + c] = (float)invstd; block[LC_XM * C + c] = (float)(-(double)rm[c] * invstd);
     block[LC_MEAN * C + c] = rm[c]; block[LC_VAR * C + c] = rv[c];
 }
-// backward: dgamma = sum dz*xhat, dbeta = sum dz; coefficients of dL/dy = dz*p0 + y*p1 + p2.
-// The conv bias feeding this BatchNorm has an analytically zero gradient (the batch mean removes it).
-struct BnBwdArgs {
-    const double* stat; const float* gamma; float* block; float* dgamma; float* dbeta; float* dconv_bias;
-    int C; double count;
-};
-__global__ void bn_bwd_finalize_kernel(BnBwdArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
-    const double sdz = a.stat[c], sdzx = a.stat[a.C + c];
-    const double invstd = a.block[LC_INVSTD * a.C + c], mean = a.block[LC_MEAN * a.C + c];
-    const double s = (double)a.gamma[c] * invstd, m1 = sdz / a.count, m2 = sdzx / a.count;
-    a.block[LC_P0 * a.C + c] = (float)s;
-    a.block[LC_P1 * a.C + c] = (float)(-s * m2 * invstd);
-    a.block[LC_P2 * a.C + c] = (float)(-s * m1 + s * m2 * mean * invstd);
-    a.dgamma[c] = (float)sdzx; a.dbeta[c] = (float)sdz;
-    if (a.dconv_bias) a.dconv_bias[c] = 0.f;
-}
-
 // ---------------------------------------------------------------------------
 // latent block.  fc_mu | fc_var partial products arrive as split-K slabs.
 struct LatentFwdArgs {

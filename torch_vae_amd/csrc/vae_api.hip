@@ -89,8 +89,11 @@ struct vae_ctx {
     void* wp_fwd[8]; void* wp_dg[8];   // indexed by BN layer id (1..7); [0] unused
     void *fcpack, *dipack;
     PackDesc* d_descs; std::vector<PackDesc> h_descs; const float* packed_for;
-    float* slab; float* slab2; size_t slab_floats;
-    hipStream_t side; hipEvent_t ev_fork, ev_join, ev_pack; int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max;
+    float* slab; size_t slab_floats;
+    // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
+    static constexpr int NSIDE = 3, NFORK = 16;
+    hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, use_fused_bn;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -123,22 +126,27 @@ template <typename T> static T* dalloc(vae_ctx* c, size_t n) {
 extern "C" void vae_destroy(vae_ctx* c) {
     if (!c) return;
     for (void* p : c->allocs) (void)hipFree(p);
-    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_pack); }
+    if (c->n_side_ok) {
+        for (int i = 0; i < vae_ctx::NSIDE; ++i) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
+        for (int i = 0; i < vae_ctx::NFORK; ++i) (void)hipEventDestroy(c->ev_fork[i]);
+        (void)hipEventDestroy(c->ev_pack);
+    }
     delete c;
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
+static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 0;   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
 static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out) {
     int WA, WB;
-    if (CA >= 64 && CB >= 64) { WA = 2; WB = 2; } else if (CB == 32 && CA >= 64) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
+    if (CA >= 64 && CB >= 64 && g_wgrad_tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && g_wgrad_tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
     const int WK = 4 / (WA * WB);
     Tiling t = make_tiling(Hs, Ws, WG_KP);
     const int TB = 1 << t.lTB;
     const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
     const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
     const size_t per = (size_t)9 * CA * CB;
-    int nsplit = std::max(1, 1024 / chan_tiles);
-    const size_t cap = (size_t)(48u << 20) / 4;  // bound slab traffic to 48 MiB per layer
+    int nsplit = std::max(1, g_wgrad_wgs / chan_tiles);
+    const size_t cap = ((size_t)g_wgrad_cap_mb << 20) / 4;  // bound slab traffic to 48 MiB per layer
     nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / per));
     nsplit = std::min(nsplit, n_tiles);
     const int tps = (n_tiles + nsplit - 1) / nsplit;
@@ -150,7 +158,8 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 1; c->side = nullptr; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 1; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
@@ -210,12 +219,16 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_di);
         slab = std::max(slab, (size_t)8 * (2 * (size_t)L * c->F + c->F));   // fc / decoder_input weight-gradient batch slices
         c->slab_floats = slab;
-        c->slab = dalloc<float>(c, slab); c->slab2 = dalloc<float>(c, slab);
-        ok = c->slab != nullptr && c->slab2 != nullptr;
-        if (ok) ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess;
+        c->slab = dalloc<float>(c, slab);
+        ok = c->slab != nullptr;
+        for (int i = 0; i < vae_ctx::NSIDE && ok; ++i) { c->side_slab[i] = dalloc<float>(c, slab); ok = c->side_slab[i] != nullptr; }
+        if (ok) {
+            for (int i = 0; i < vae_ctx::NSIDE && ok; ++i)
+                ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < vae_ctx::NFORK && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess;
+            c->n_side_ok = ok ? 1 : 0;
+        }
     }
     if (!ok) { vae_set_error("vae_create", "hipMalloc failed"); vae_destroy(c); return nullptr; }
     std::vector<float> id(3 * 256, 0.f);
@@ -237,6 +250,10 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_side_stream")) { c->use_side_stream = value; return 0; }
     if (!strcmp(name, "knob_bwd_per_cu")) { c->knob_bwd_per_cu = value; return 0; }
     if (!strcmp(name, "knob_wave_nt_max")) { c->knob_wave_nt_max = value; return 0; }
+    if (!strcmp(name, "use_fused_bn")) { c->use_fused_bn = value; return 0; }
+    if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
+    if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
+    if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
     return vae_set_error("vae_set_option", "unknown option");
 }
 
@@ -347,7 +364,8 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     return 0;
 }
 
-static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int CA, int CB, hipStream_t st) {
+static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int CA, int CB, hipStream_t st, vae_ctx* c = nullptr) {
+    ProfScope ps(c, "reduce_slab", 4.0 * n * (nslab + 1), 0, st);
     hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB);
     LAUNCH_CHECK("reduce_slab_kernel");
     return 0;
@@ -388,7 +406,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     LAUNCH_CHECK("wgrad_kernel");
     }
     (void)WK;
-    return launch_reduce(slab_buf, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st);
+    return launch_reduce(slab_buf, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st, c);
 }
 
 template <typename T>
@@ -496,23 +514,50 @@ static int pack_weights(vae_ctx* c, const float* params, hipStream_t st) {
     return 0;
 }
 
-static int bn_finalize_fwd(vae_ctx* c, int i, const float* params, float* bn_running, int64_t* nbt, int train, hipStream_t st) {
+// ---- BatchNorm finalisation: folded into the consumer's prologue (BnFuse, common.cuh) or a standalone launch ----
+static BnFuse make_fuse_fwd(vae_ctx* c, int i, const float* params, float* bn_running, int64_t* nbt) {
     const BnLayer& l = c->lay[i];
-    if (train) {
-        BnFwdArgs a;
-        a.stat = l.stat_f; a.gamma = params + c->poff[l.p_gamma]; a.beta = params + c->poff[l.p_beta]; a.block = l.block;
-        a.running_mean = bn_running ? bn_running + c->bnoff[i] : nullptr; a.running_var = bn_running ? bn_running + c->bnoff[i] + l.C : nullptr;
-        a.nbt = nbt ? reinterpret_cast<long long*>(nbt) + i : nullptr;
-        a.C = l.C; a.count = (double)c->B * l.H * l.W; a.eps = kBnEps; a.momentum = kBnMom; a.update_running = bn_running != nullptr;
-        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, a);
-    } else {
-        if (!bn_running) return vae_set_error("vae_forward", "eval mode needs running statistics");
-        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(1), dim3(256), 0, st, params + c->poff[l.p_gamma], params + c->poff[l.p_beta],
-                           bn_running + c->bnoff[i], bn_running + c->bnoff[i] + l.C, l.block, l.C, kBnEps);
-    }
-    LAUNCH_CHECK("bn_finalize");
+    BnFuse f; memset(&f, 0, sizeof(f));
+    f.stat = l.stat_f; f.gamma = params + c->poff[l.p_gamma]; f.beta = params + c->poff[l.p_beta]; f.block = l.block;
+    f.running_mean = bn_running ? bn_running + c->bnoff[i] : nullptr; f.running_var = bn_running ? bn_running + c->bnoff[i] + l.C : nullptr;
+    f.nbt = nbt ? reinterpret_cast<long long*>(nbt) + i : nullptr;
+    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.eps = kBnEps; f.momentum = kBnMom; f.update_running = bn_running != nullptr;
+    f.mode = BNF_FWD;
+    return f;
+}
+static BnFuse make_fuse_bwd(vae_ctx* c, int i, const float* params, float* grads) {
+    const BnLayer& l = c->lay[i];
+    BnFuse f; memset(&f, 0, sizeof(f));
+    f.stat = l.stat_b; f.gamma = params + c->poff[l.p_gamma]; f.block = l.block;
+    f.dgamma = grads + c->poff[l.p_gamma]; f.dbeta = grads + c->poff[l.p_beta]; f.dconv_bias = grads + c->poff[l.p_convb];
+    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.mode = BNF_BWD;
+    return f;
+}
+static int bn_finalize_now(vae_ctx* c, const BnFuse& f, hipStream_t st) {
+    ProfScope ps(c, f.mode == BNF_FWD ? "bn_fwd_finalize" : "bn_bwd_finalize", 0, 0, st);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    LAUNCH_CHECK("bn_finalize_kernel");
     return 0;
 }
+// Coefficients of layer i for the kernel that stages its tensor next.  Train mode with a fusing consumer: returns
+// the BnFuse descriptor (mode BNF_FWD) and launches nothing; otherwise the block is filled by a standalone launch
+// (batch statistics, or running statistics in eval mode) and the returned descriptor has mode BNF_NONE.
+static int input_bn_fwd(vae_ctx* c, int i, const float* params, float* bn_running, int64_t* nbt, int train, bool consumer_fuses,
+                        BnFuse* out, hipStream_t st) {
+    memset(out, 0, sizeof(*out));
+    const BnLayer& l = c->lay[i];
+    if (train) {
+        BnFuse f = make_fuse_fwd(c, i, params, bn_running, nbt);
+        if (consumer_fuses && c->use_fused_bn) { *out = f; return 0; }
+        return bn_finalize_now(c, f, st);
+    }
+    if (!bn_running) return vae_set_error("vae_forward", "eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(1), dim3(256), 0, st, params + c->poff[l.p_gamma], params + c->poff[l.p_beta],
+                       bn_running + c->bnoff[i], bn_running + c->bnoff[i] + l.C, l.block, l.C, kBnEps);
+    LAUNCH_CHECK("bn_eval_coef_kernel");
+    return 0;
+}
+template <typename T> static bool will_pipe(vae_ctx* c, const ConvArgs<T>& a) { return c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a); }
 
 // decoder half of the forward (models.py:147-175): decoder_input -> 3x ConvT blocks -> final_layer
 // Weight gradients are consumed only by the optimiser: with use_side_stream they run on the context's side
@@ -520,14 +565,25 @@ static int bn_finalize_fwd(vae_ctx* c, int i, const float* params, float* bn_run
 // input-gradient chain - the critical path of the backward - continues on the caller's stream; the two are
 // joined at the end of vae_backward.  fork_side returns the stream (and slab) the forked work should use.
 struct SideFork { hipStream_t st; float* slab; int rc; };
-static SideFork fork_side(vae_ctx* c, hipStream_t st) {
+static SideFork fork_side(vae_ctx* c, hipStream_t st, int which = -1) {
     SideFork f{st, c->slab, 0};
     if (!c->use_side_stream) return f;
-    if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) {
+    const int s = which >= 0 ? which : (c->side_rr++ % vae_ctx::NSIDE);
+    hipEvent_t ev = c->ev_fork[c->fork_rr++ % vae_ctx::NFORK];
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(c->side[s], ev, 0) != hipSuccess) {
         f.rc = vae_set_error("fork_side", "event record/wait failed"); return f;
     }
-    f.st = c->side; f.slab = c->slab2;
+    f.st = c->side[s]; f.slab = c->side_slab[s];
     return f;
+}
+// join every side stream into `st`
+static int join_sides(vae_ctx* c, hipStream_t st) {
+    if (!c->use_side_stream) return 0;
+    for (int i = 0; i < vae_ctx::NSIDE; ++i) {
+        HIP_CHECK_RET(hipEventRecord(c->ev_join[i], c->side[i]));
+        HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_join[i], 0));
+    }
+    return 0;
 }
 template <typename T>
 static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
@@ -551,8 +607,8 @@ static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, f
         a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
         a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
         a.B = B; a.Hs = c->lay[i].H / 2; a.Ws = c->lay[i].W / 2; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
+        if (i > 4 && input_bn_fwd(c, i - 1, params, bn_running, nbt, train, will_pipe(c, a), &a.fuse, st)) return -1;
         if (launch_up<T>(c, a, st)) return -1;
-        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
     }
     // output conv + sigmoid + reconstruction loss/gradient
     c->tag = "final_layer.3";
@@ -561,9 +617,12 @@ static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, f
         a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
         a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
         a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
+        const bool mfma_out = sizeof(T) == 2 && c->use_mfma_convout;
+        BnFuse f7;
+        if (input_bn_fwd(c, 7, params, bn_running, nbt, train, mfma_out, &f7, st)) return -1;
         ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
-        if (sizeof(T) == 2 && c->use_mfma_convout) {
-            ConvOutFwdMfmaArgs m;
+        if (mfma_out) {
+            ConvOutFwdMfmaArgs m; m.fuse = f7;
             m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.coef = a.coef; m.wt = a.wt; m.bias = a.bias; m.target = x;
             m.xhat = xhat; m.dlogit = c->dlogit; m.accum = c->accum; m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
             m.inv_n = a.inv_n; m.slope = kSlope;
@@ -589,7 +648,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         SideFork f = fork_side(c, st);
         if (f.rc) return f.rc;
         if (pack_weights<T>(c, params, f.st)) return -1;
-        if (c->use_side_stream) HIP_CHECK_RET(hipEventRecord(c->ev_pack, c->side));
+        if (c->use_side_stream) HIP_CHECK_RET(hipEventRecord(c->ev_pack, f.st));
     }
     {
         const long P = (long)B * (H / 2) * (H / 2);
@@ -598,7 +657,6 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
         LAUNCH_CHECK("conv1_fwd_kernel");
-        if (bn_finalize_fwd(c, 0, params, bn_running, nbt, train, st)) return -1;
         if (c->use_side_stream) HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_pack, 0));
     }
     for (int i = 1; i < 4; ++i) {
@@ -608,8 +666,8 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         a.wp = reinterpret_cast<const T*>(c->wp_fwd[i]); a.bias = params + c->poff[c->lay[i].p_convb];
         a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
         a.B = B; a.Hs = c->lay[i].H; a.Ws = c->lay[i].W; a.Cin = c->lay[i - 1].C; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
+        if (input_bn_fwd(c, i - 1, params, bn_running, nbt, train, will_pipe(c, a), &a.fuse, st)) return -1;
         if (launch_down<T>(c, a, st)) return -1;
-        if (bn_finalize_fwd(c, i, params, bn_running, nbt, train, st)) return -1;
     }
     // fc_mu | fc_var, reparameterize
     c->tag = "latent";
@@ -617,6 +675,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         DenseArgs<T> a; memset(&a, 0, sizeof(a));
         a.A = reinterpret_cast<const T*>(c->lay[3].y); a.coef = c->lay[3].block; a.slope = kSlope; a.C = 256;
         a.Bp = reinterpret_cast<const T*>(c->fcpack); a.M = B; a.K = (int)c->F; a.Npad = c->npad_fc;
+        if (input_bn_fwd(c, 3, params, bn_running, nbt, train, true, &a.fuse, st)) return -1;
         int nsplit;
         if (launch_dense<T>(c, a, &nsplit, st)) return -1;
         if (eps) HIP_CHECK_RET(hipMemcpyAsync(c->eps, eps, (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
@@ -633,16 +692,6 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     return decode_impl<T>(c, z, B, params, bn_running, nbt, train, x, xhat, st);
 }
 
-static int bn_finalize_bwd(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
-    const BnLayer& l = c->lay[i];
-    BnBwdArgs a;
-    a.stat = l.stat_b; a.gamma = params + c->poff[l.p_gamma]; a.block = l.block;
-    a.dgamma = grads + c->poff[l.p_gamma]; a.dbeta = grads + c->poff[l.p_beta]; a.dconv_bias = grads + c->poff[l.p_convb];
-    a.C = l.C; a.count = (double)c->B * l.H * l.W;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, a);
-    LAUNCH_CHECK("bn_bwd_finalize_kernel");
-    return 0;
-}
 
 template <typename T>
 static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t st) {
@@ -677,7 +726,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     {
         ConvOutBwdArgs a;
         a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
-        a.dz = c->lay[7].dz; a.slab = c->use_side_stream ? c->slab2 : c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
+        a.dz = c->lay[7].dz; a.slab = c->use_side_stream ? c->side_slab[0] : c->slab; a.stat = c->lay[7].stat_b; a.dbias = c->accum + 2; a.B = B; a.H = H; a.W = H; a.slope = kSlope;
         const long P = (long)B * H * H;
         int grid = (int)std::min<long>((P + 63) / 64, 1024);
         ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
@@ -695,7 +744,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         LAUNCH_CHECK("convout_bwd_kernel");
     }
     {
-        SideFork f = fork_side(c, st);
+        SideFork f = fork_side(c, st, 0);   // the kernel above wrote its partial sums into side stream 0's slab
         if (f.rc) return f.rc;
         if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st)) return -1;
         hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39], 1, 1.f);
@@ -704,7 +753,6 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
     for (int i = 7; i >= 4; --i) {
         c->tag = kLayerTag[i];
-        if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
         const BnLayer& l = c->lay[i];
         const int Cin = i == 4 ? 256 : c->lay[i - 1].C;
         WgradArgs<T> w; memset(&w, 0, sizeof(w));
@@ -713,7 +761,6 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         w.s_two = 0;
         w.g0 = reinterpret_cast<const T*>(l.dz); w.g1 = reinterpret_cast<const T*>(l.y); w.gcoef = l.block + LC_P0 * l.C; w.gslope = 1.f; w.g_two = 1;
         w.B = B; w.Hs = l.H / 2; w.Ws = l.W / 2; w.CA = Cin; w.CB = l.C;
-        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
         a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
@@ -723,6 +770,11 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
             a.out = reinterpret_cast<T*>(c->lay[i - 1].dz); a.yout = reinterpret_cast<const T*>(c->lay[i - 1].y);
             a.ocoef = c->lay[i - 1].block; a.oslope = kSlope; a.stat = c->lay[i - 1].stat_b; a.epi = EPI_BWD;
         }
+        // BatchNorm backward of this layer: folded into both consumers (the input-gradient kernel records it)
+        BnFuse fb = make_fuse_bwd(c, i, params, grads);
+        if (!(c->use_fused_bn && will_pipe(c, a))) { if (bn_finalize_now(c, fb, st)) return -1; fb.mode = BNF_NONE; }
+        w.fuse = fb; a.fuse = fb;
+        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         if (launch_down<T>(c, a, st)) return -1;
     }
     // decoder_input backward, reparameterisation + KL backward
@@ -786,23 +838,25 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
     for (int i = 3; i >= 1; --i) {
         c->tag = kLayerTag[i];
-        if (bn_finalize_bwd(c, i, params, grads, st)) return -1;
         const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
         WgradArgs<T> w; memset(&w, 0, sizeof(w));
         w.s0 = reinterpret_cast<const T*>(l.dz); w.s1 = reinterpret_cast<const T*>(l.y); w.scoef = l.block + LC_P0 * l.C; w.sslope = 1.f; w.s_two = 1;
         w.g0 = reinterpret_cast<const T*>(lp.y); w.gcoef = lp.block; w.gslope = kSlope; w.g_two = 0;
         w.B = B; w.Hs = l.H; w.Ws = l.W; w.CA = l.C; w.CB = lp.C;
-        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         ConvArgs<T> a; memset(&a, 0, sizeof(a));
         a.src0 = reinterpret_cast<const T*>(l.dz); a.src1 = reinterpret_cast<const T*>(l.y); a.coef = l.block + LC_P0 * l.C; a.slope = 1.f; a.two_src = 1;
         a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
         a.out = reinterpret_cast<T*>(lp.dz); a.yout = reinterpret_cast<const T*>(lp.y); a.ocoef = lp.block; a.oslope = kSlope; a.stat = lp.stat_b; a.epi = EPI_BWD;
         a.B = B; a.Hs = l.H; a.Ws = l.W; a.Cin = l.C; a.Cout = lp.C;
+        BnFuse fb = make_fuse_bwd(c, i, params, grads);
+        if (!(c->use_fused_bn && will_pipe(c, a))) { if (bn_finalize_now(c, fb, st)) return -1; fb.mode = BNF_NONE; }
+        w.fuse = fb; a.fuse = fb;
+        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         if (launch_up<T>(c, a, st)) return -1;
     }
     {
         c->tag = kLayerTag[0];
-        if (bn_finalize_bwd(c, 0, params, grads, st)) return -1;
+        if (bn_finalize_now(c, make_fuse_bwd(c, 0, params, grads), st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
         SideFork f = fork_side(c, st);
@@ -813,11 +867,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         LAUNCH_CHECK("conv1_wgrad_kernel");
         if (launch_reduce(f.slab, grid, 288, grads + c->poff[0], 32, 1, f.st)) return -1;
     }
-    if (c->use_side_stream) {
-        HIP_CHECK_RET(hipEventRecord(c->ev_join, c->side));
-        HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_join, 0));
-    }
-    return 0;
+    return join_sides(c, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -952,6 +1002,24 @@ extern "C" int vae_profile_sequence(vae_ctx* c, char* buf, int64_t cap) {
     for (size_t i = 0; i < c->prof_recs.size(); ++i) out += std::string(i ? "," : "") + "\"" + c->prof_recs[i].name + "\"";
     out += "]";
     if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_sequence", "buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
+// JSON: [[name, start_ms, end_ms], ...] relative to the first recorded launch (shows the overlap of the two streams)
+extern "C" int vae_profile_timeline(vae_ctx* c, char* buf, int64_t cap) {
+    if (!c) return vae_set_error("vae_profile_timeline", "null ctx");
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    std::string out = "[";
+    for (size_t i = 0; i < c->prof_recs.size(); ++i) {
+        float t0 = 0.f, t1 = 0.f;
+        (void)hipEventElapsedTime(&t0, c->prof_recs[0].e0, c->prof_recs[i].e0);
+        (void)hipEventElapsedTime(&t1, c->prof_recs[0].e0, c->prof_recs[i].e1);
+        char tmp[64]; snprintf(tmp, sizeof(tmp), "\",%.4f,%.4f]", t0, t1);
+        out += std::string(i ? ",[\"" : "[\"") + c->prof_recs[i].name + tmp;
+    }
+    out += "]";
+    if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_timeline", "buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
