@@ -98,7 +98,9 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 //   v = leaky( t0 * p0[c] + t1 * p1[c] + p2[c], slope )
 // activation load : t0 = raw conv output y, p = (gamma*invstd, 0, beta - mean*gamma*invstd), slope 0.01
 // gradient load   : t0 = dz, t1 = y, p = BatchNorm-backward coefficients, slope 1
-__device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
+// LeakyReLU for 0 <= slope <= 1 (0.01 in the model, 1 = identity for gradient operands): max(z, slope*z) is the
+// same value as the select form, in two instructions instead of three
+__device__ __forceinline__ float leaky(float z, float slope) { return fmaxf(z, z * slope); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -17,6 +17,12 @@
 
 struct TileGeo { int b0, y0, x0, n0; };
 
+// uniform base + 32-bit BYTE offset: lets the compiler use the scalar-base addressing mode of global_load/store
+// (no 64-bit vector address arithmetic); the launcher guarantees every tensor is < 4 GiB
+template <typename P> __device__ __forceinline__ P* at_bytes(P* base, uint32_t byte_off) {
+    return reinterpret_cast<P*>(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off);
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // round a pair the way it is stored (one packed conversion for bf16) and return the stored values as f32
@@ -85,11 +91,13 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     char* mytile = otile + wave * 32 * OPITCH;
     // per-item staging table (tile-independent): {relative global element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
     int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
-    for (int it = tid; it < nitems; it += 256) {
+    // (padded to MAXI*SSTR entries; padding entries carry image 0xffff, which never passes the batch test)
+    for (int it = tid; it < max(nitems, MAXI * SSTR); it += 256) {
         const int pix = it >> 2, q = it & 3;
         const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-        itab[it] = make_int2(((img * Hin + py) * Win + px) * Cin + q * E16,
-                             ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15));
+        itab[it] = it < nitems ? make_int2(((img * Hin + py) * Win + px) * Cin + q * E16,
+                                           ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15))
+                               : make_int2(0, 0xffff << 15);
     }
 
     if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
@@ -141,9 +149,18 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     auto xform = [&](const Vec16<T>& v0, const Vec16<T>& v1) __attribute__((always_inline)) {
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if constexpr (TWO_SRC) o.set(e, v0.get(e) * k0[e] + v1.get(e) * k1[e] + k2[e]);
-            else o.set(e, leaky(v0.get(e) * k0[e] + k2[e], a.slope));
+        for (int e = 0; e < NE; e += 2) {   // pairs: packed f32 multiply-adds
+            const f32x2 x0 = {v0.get(e), v0.get(e + 1)}, c0 = {k0[e], k0[e + 1]}, c2 = {k2[e], k2[e + 1]};
+            f32x2 z;
+            if constexpr (TWO_SRC) {
+                const f32x2 x1 = {v1.get(e), v1.get(e + 1)}, c1 = {k1[e], k1[e + 1]};
+                z = x0 * c0 + x1 * c1 + c2;
+            } else {
+                z = x0 * c0 + c2;
+                const f32x2 zs = z * a.slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+            }
+            o.set(e, z.x); o.set(e + 1, z.y);
         }
         return o;
     };
@@ -157,25 +174,26 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         return ((g.b0 * Hin + 2 * g.y0 - 1) * Win + 2 * g.x0 - 1) * Cin + c0;
     };
     auto item_ok = [&](const TileGeo& g, int it, int ey) __attribute__((always_inline)) {
-        // the halo row/column (py==0 / px==0) falls outside the image only for tiles on the top / left border
-        return (it < nitems) & ((g.b0 + (ey >> 15)) < a.B) & !(((ey >> 13) & 1) & (g.y0 == 0)) & !(((ey >> 14) & 1) & (g.x0 == 0));
+        // the halo row/column (py==0 / px==0: flag bits 13/14) falls outside the image only for tiles on the top / left border
+        const int tmask = (g.y0 == 0 ? 1 << 13 : 0) | (g.x0 == 0 ? 1 << 14 : 0);   // uniform per tile
+        return ((ey & tmask) == 0) & ((ey >> 15) < a.B - g.b0);
     };
     auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
         const int base = tile_base(g, c0);
         int2 e[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it < nitems ? it : 0]; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it]; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const uint32_t gi = item_ok(g, stid + u * SSTR, e[u].y) ? (uint32_t)(base + e[u].x) : 0u;
-            pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
-            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
+            pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
+            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
     };
     auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
         int ey[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it < nitems ? it : 0].y; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it].y; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
             int loff; const int gi = out_chunk_addr(g, u, loff);
-            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
+            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(at_bytes(a.yout, (uint32_t)(gi < 0 ? 0 : gi) * (uint32_t)sizeof(T)));
         }
     };
 
@@ -256,9 +274,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             auto load_b = [&](int t, int slot) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const size_t kg = (size_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+                    const uint32_t kg = (uint32_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq[slot][ks][nt] = load_frag(a.wp + (kg * Cout + cur.n0 + nt * 32 + r) * 8);
+                    for (int nt = 0; nt < NT; ++nt) bq[slot][ks][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + nt * 32 + r) * (uint32_t)(8 * sizeof(T))));
                 }
             };
 #pragma unroll
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             for (int u = 0; u < OPL; ++u) {
                 int loff; const int gi = out_chunk_addr(cur, u, loff);
                 const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mytile + loff);
-                if (gi >= 0) *reinterpret_cast<Vec16<T>*>(a.out + gi) = v;
+                if (gi >= 0) *reinterpret_cast<Vec16<T>*>(at_bytes(a.out, (uint32_t)gi * (uint32_t)sizeof(T))) = v;
             }
         }
         STAMP(5)
@@ -365,13 +383,14 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     char* otile = patch0 + (WV ? 4 : 1) * npix * PATCH_PITCH;                 // [4 waves][64 px][OPITCH]
     float* red = reinterpret_cast<float*>(otile + 256 * OPITCH);
     char* mytile = otile + wave * 64 * OPITCH;
-    // per-item staging table: {relative global element offset, LDS offset/16 | row<<13 | col<<19 | img<<25}
+    // per-item staging table: {relative global element offset, LDS offset/16 | bottom-halo<<13 | right-halo<<14 | img<<15}
     int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
-    for (int it = tid; it < nitems; it += 256) {
+    for (int it = tid; it < max(nitems, MAXI * SSTR); it += 256) {
         const int pix = it >> 2, q = it & 3;
         const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-        itab[it] = make_int2(((img * Hs + py) * Ws + px) * Cin + q * E16,
-                             ((pix * PATCH_PITCH + q * 16) >> 4) | (py << 13) | (px << 19) | (img << 25));
+        itab[it] = it < nitems ? make_int2(((img * Hs + py) * Ws + px) * Cin + q * E16,
+                                           ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == th) << 13) | ((px == tw) << 14) | (img << 15))
+                               : make_int2(0, 0xffff << 15);
     }
 
     if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
@@ -415,9 +434,20 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     auto xform = [&](const Vec16<T>& v0, const Vec16<T>& v1) __attribute__((always_inline)) {
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if constexpr (TWO_SRC) o.set(e, v0.get(e) * cf[kcb + e] + v1.get(e) * cf[Cin + kcb + e] + cf[2 * Cin + kcb + e]);
-            else o.set(e, leaky(v0.get(e) * k0[e] + k2[e], a.slope));
+        for (int e = 0; e < NE; e += 2) {   // pairs: packed f32 multiply-adds
+            const f32x2 x0 = {v0.get(e), v0.get(e + 1)};
+            f32x2 z;
+            if constexpr (TWO_SRC) {
+                const f32x2 x1 = {v1.get(e), v1.get(e + 1)};
+                const f32x2 c0 = {cf[kcb + e], cf[kcb + e + 1]}, c1 = {cf[Cin + kcb + e], cf[Cin + kcb + e + 1]}, c2 = {cf[2 * Cin + kcb + e], cf[2 * Cin + kcb + e + 1]};
+                z = x0 * c0 + x1 * c1 + c2;
+            } else {
+                const f32x2 c0 = {k0[e], k0[e + 1]}, c2 = {k2[e], k2[e + 1]};
+                z = x0 * c0 + c2;
+                const f32x2 zs = z * a.slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+            }
+            o.set(e, z.x); o.set(e + 1, z.y);
         }
         return o;
     };
@@ -428,25 +458,26 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         return ((g.b0 * Hs + g.y0) * Ws + g.x0) * Cin + c0;
     };
     auto item_ok = [&](const TileGeo& g, int it, int ey) __attribute__((always_inline)) {
-        // the bottom/right halo (row th, column tw) leaves the image only on the last tile row / column
-        return (it < nitems) & ((g.b0 + (ey >> 25)) < a.B) & ((g.y0 + ((ey >> 13) & 63)) < Hs) & ((g.x0 + ((ey >> 19) & 63)) < Ws);
+        // the bottom/right halo (row th, column tw: flag bits 13/14) leaves the image only on the last tile row / column
+        const int tmask = (g.y0 + th >= Hs ? 1 << 13 : 0) | (g.x0 + tw >= Ws ? 1 << 14 : 0);   // uniform per tile
+        return ((ey & tmask) == 0) & ((ey >> 15) < a.B - g.b0);
     };
     auto issue = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
         const int base = tile_base(g, c0);
         int2 e[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it < nitems ? it : 0]; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it]; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const uint32_t gi = item_ok(g, stid + u * SSTR, e[u].y) ? (uint32_t)(base + e[u].x) : 0u;
-            pre0[u] = *reinterpret_cast<const Vec16<T>*>(a.src0 + gi);
-            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(a.src1 + gi);
+            pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
+            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
     };
     auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
         int ey[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it < nitems ? it : 0].y; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it].y; }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
 #pragma unroll
         for (int u = 0; u < OPL; ++u) {
             int loff; const int gi = out_chunk_addr(g, py, u, loff);
-            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(a.yout + (gi < 0 ? 0 : gi));
+            prey[u] = *reinterpret_cast<const decltype(Vec16<T>::v)*>(at_bytes(a.yout, (uint32_t)(gi < 0 ? 0 : gi) * (uint32_t)sizeof(T)));
         }
     };
 
@@ -540,9 +571,9 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             constexpr int DEPTH = (NT <= 1 ? 4 : 2);
             Frag<T> bq[DEPTH][NT];
             auto load_b = [&](int k, int slot) {
-                const size_t kg = (size_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+                const uint32_t kg = (uint32_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[slot][nt] = load_frag(a.wp + (kg * Cout + cur.n0 + nt * 32 + r) * 8);
+                for (int nt = 0; nt < NT; ++nt) bq[slot][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + nt * 32 + r) * (uint32_t)(8 * sizeof(T))));
             };
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) load_b(d, d);
@@ -594,7 +625,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 for (int u = 0; u < OPL; ++u) {
                     int loff; const int gi = out_chunk_addr(cur, py, u, loff);
                     const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mytile + loff);
-                    if (gi >= 0) *reinterpret_cast<Vec16<T>*>(a.out + gi) = v;
+                    if (gi >= 0) *reinterpret_cast<Vec16<T>*>(at_bytes(a.out, (uint32_t)gi * (uint32_t)sizeof(T))) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before round 1 overwrites the tile
             }

@@ -268,8 +268,8 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 }
 
 template <typename T> static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st);
-// the pipelined kernels index their tensors with 32-bit element offsets
-template <typename T> static bool fits_i32(const ConvArgs<T>& a) { return 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) < 2147483648.0; }
+// the pipelined kernels index their tensors with 32-bit byte offsets (and signed 32-bit element offsets)
+template <typename T> static bool fits_i32(const ConvArgs<T>& a) { return 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) * sizeof(T) < 4294967296.0 && 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) < 2147483648.0; }
 
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
@@ -335,7 +335,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
-                       (size_t)TB * PHW * 4 * 8;   // + the per-item staging table
+                       std::max<size_t>((size_t)TB * PHW * 4, (size_t)(is_down ? 10 : 3) * (wv ? 64 : 256)) * 8;   // + the per-item staging table (padded to MAXI*SSTR)
     if (lds > 160 * 1024) return vae_set_error("conv_pipe", "tile does not fit LDS");
     if (c->knob_ablate_b) a.two_src |= 2;
     a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
