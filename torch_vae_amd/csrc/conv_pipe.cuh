@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             f32x2 z;
             if constexpr (TWO_SRC) {
                 const f32x2 x1 = {v1.get(e), v1.get(e + 1)}, c1 = {k1[e], k1[e + 1]};
-                z = x0 * c0 + x1 * c1 + c2;
+                z = x0 * c0 + (x1 * c1 + c2);   // two packed fmas
             } else {
                 z = x0 * c0 + c2;
                 const f32x2 zs = z * a.slope;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             if constexpr (TWO_SRC) {
                 const f32x2 x1 = {v1.get(e), v1.get(e + 1)};
                 const f32x2 c0 = {cf[kcb + e], cf[kcb + e + 1]}, c1 = {cf[Cin + kcb + e], cf[Cin + kcb + e + 1]}, c2 = {cf[2 * Cin + kcb + e], cf[2 * Cin + kcb + e + 1]};
-                z = x0 * c0 + x1 * c1 + c2;
+                z = x0 * c0 + (x1 * c1 + c2);   // two packed fmas
             } else {
                 const f32x2 c0 = {k0[e], k0[e + 1]}, c2 = {k2[e], k2[e + 1]};
                 z = x0 * c0 + c2;

@@ -56,23 +56,37 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(cg * 8 + c) * 9 + t];
     }
-    for (int p = blockIdx.x * 64 + slot; p < P; p += gridDim.x * 64) {
-        const int ox = p & (Wo - 1), oy = (p >> lw) & (Ho - 1); const size_t b = p >> (lw + lh);
-        float xv[9];
+    // UNR pixels per thread per trip: all their input taps are requested before any is used (the loop is latency-bound)
+    constexpr int UNR = 4;
+    for (int p0 = blockIdx.x * 64 + slot; p0 < P; p0 += gridDim.x * 64 * UNR) {
+        float xv[UNR][9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-            xv[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(b * H + iy) * W + ix] : 0.f;
+        for (int u = 0; u < UNR; ++u) {
+            const int p = p0 + u * gridDim.x * 64, pc = p < P ? p : 0;
+            const int ox = pc & (Wo - 1), oy = (pc >> lw) & (Ho - 1), b = pc >> (lw + lh);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float v = x[in ? (b * H + iy) * W + ix : 0];
+                xv[u][t] = in ? v : 0.f;
+            }
         }
-        float o[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float acc = br[c];
+        for (int u = 0; u < UNR; ++u) {
+            const int p = p0 + u * gridDim.x * 64;
+            if (p < P) {
+                float o[8];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc += wr[c][t] * xv[t];
-            o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
+                for (int c = 0; c < 8; ++c) {
+                    float acc = br[c];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc += wr[c][t] * xv[u][t];
+                    o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
+                }
+                store8<T>(y + (size_t)p * 32 + cg * 8, o);
+            }
         }
-        store8<T>(y + (size_t)p * 32 + cg * 8, o);
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -105,20 +119,30 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
     }
-    for (int p = blockIdx.x * 64 + slot; p < P; p += gridDim.x * 64) {
-        const int ox = p & (Wo - 1), oy = (p >> lw) & (Ho - 1); const size_t b = p >> (lw + lh);
-        float xv[9], dv[8], yv[8];
+    constexpr int UNR = 2;   // pixels per thread per trip, all loads issued before use (latency-bound loop)
+    for (int q0 = blockIdx.x * 64 + slot; q0 < P; q0 += gridDim.x * 64 * UNR) {
+        float xv[UNR][9], dv[UNR][8], yv[UNR][8];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-            xv[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(b * H + iy) * W + ix] : 0.f;
+        for (int u = 0; u < UNR; ++u) {
+            const int p = q0 + u * gridDim.x * 64, pc = p < P ? p : 0;
+            const int ox = pc & (Wo - 1), oy = (pc >> lw) & (Ho - 1), b = pc >> (lw + lh);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+                const bool in = p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float v = x[in ? (b * H + iy) * W + ix : 0];
+                xv[u][t] = in ? v : 0.f;    // pixels beyond the end contribute nothing
+            }
+            load8<T>(dz + (size_t)pc * 32 + cg * 8, dv[u]); load8<T>(y + (size_t)pc * 32 + cg * 8, yv[u]);
         }
-        load8<T>(dz + (size_t)p * 32 + cg * 8, dv); load8<T>(y + (size_t)p * 32 + cg * 8, yv);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float g = dv[c] * p0[c] + yv[c] * p1[c] + p2[c];
+        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[c][t] += g * xv[t];
+            for (int c = 0; c < 8; ++c) {
+                const float g = dv[u][c] * p0[c] + yv[u][c] * p1[c] + p2[c];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] += g * xv[u][t];
+            }
         }
     }
 #pragma unroll
