@@ -651,18 +651,27 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
         b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
     };
     bf16x8 pre[MAXI]; int ok[MAXI]; float pretg;
+    // chunk id = tid + 256u: patch pixel id>>2, channel quarter id&3 = tid&3 - the same quarter for every chunk of a thread
     auto prefetch = [&](int tile) {
         int b, y0, x0; tile_origin(tile, b, y0, x0);
         pretg = a.target[((size_t)b * a.H + y0 + (tid >> 5)) * a.W + x0 + (tid & 31)];
+        const int base = ((b * a.H + y0 - 1) * a.W + x0 - 1) * 32 + (tid & 3) * 8;
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int id = tid + 256 * u, pix = id >> 2, qq = id & 3;
+            const int id = tid + 256 * u, pix = id >> 2;
             const int py = pix / PW, px = pix - py * PW, gy = y0 - 1 + py, gx = x0 - 1 + px;
             ok[u] = id < NCHK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const size_t g = ok[u] ? (((size_t)b * a.H + gy) * a.W + gx) * 32 + qq * 8 : 0;
-            pre[u] = *reinterpret_cast<const bf16x8*>(a.yf + g);
+            const uint32_t g = ok[u] ? (uint32_t)(base + (py * a.W + px) * 32) * 2u : 0u;   // byte offset (< 4 GiB: host check)
+            pre[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.yf) + g);
         }
     };
+    __syncthreads();                     // cf published
+    f32x2 kc[4], kh[4];                  // this thread's 8 channels: scale / shift pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        kc[e] = f32x2{cf[(tid & 3) * 8 + 2 * e], cf[(tid & 3) * 8 + 2 * e + 1]};
+        kh[e] = f32x2{cf[32 + (tid & 3) * 8 + 2 * e], cf[32 + (tid & 3) * 8 + 2 * e + 1]};
+    }
 
     int tile = blockIdx.x;
     if (tile < a.n_tiles) prefetch(tile);
@@ -672,13 +681,16 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int id = tid + 256 * u;
-            if (id < NCHK) {
-                const int qq = id & 3;
-                bf16x8 o;
+            bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)(ok[u] ? leaky((float)pre[u][e] * cf[qq * 8 + e] + cf[32 + qq * 8 + e], a.slope) : 0.f);
-                *reinterpret_cast<bf16x8*>(atile + (id >> 2) * PITCH + qq * 16) = o;
+            for (int e = 0; e < 4; ++e) {
+                f32x2 z = f32x2{(float)pre[u][2 * e], (float)pre[u][2 * e + 1]} * kc[e] + kh[e];
+                const f32x2 zs = z * a.slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+                o[2 * e] = (bf16)z.x; o[2 * e + 1] = (bf16)z.y;
             }
+            if (!ok[u]) o = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (id < NCHK) *reinterpret_cast<bf16x8*>(atile + (id >> 2) * PITCH + (id & 3) * 16) = o;
         }
         __syncthreads();
         const float tg = pretg;

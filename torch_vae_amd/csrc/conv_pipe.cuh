@@ -23,8 +23,6 @@ template <typename P> __device__ __forceinline__ P* at_bytes(P* base, uint32_t b
     return reinterpret_cast<P*>(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off);
 }
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // round a pair the way it is stored (one packed conversion for bf16) and return the stored values as f32
 template <typename T> __device__ __forceinline__ f32x2 round_pair(f32x2 v, T& o0, T& o1);
 template <> __device__ __forceinline__ f32x2 round_pair<float>(f32x2 v, float& o0, float& o1) { o0 = v.x; o1 = v.y; return v; }

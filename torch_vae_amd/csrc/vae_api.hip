@@ -617,7 +617,7 @@ static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, f
         a.yf = c->lay[7].y; a.coef = c->lay[7].block; a.wt = c->wout_t; a.bias = params + c->poff[39]; a.target = x;
         a.xhat = xhat; a.dlogit = c->dlogit; a.accum = c->accum; a.B = B; a.H = H; a.W = H;
         a.inv_n = (float)(1.0 / ((double)B * H * H)); a.slope = kSlope;
-        const bool mfma_out = sizeof(T) == 2 && c->use_mfma_convout;
+        const bool mfma_out = sizeof(T) == 2 && c->use_mfma_convout && 64.0 * B * H * H < 4294967296.0;   // 32-bit byte offsets
         BnFuse f7;
         if (input_bn_fwd(c, 7, params, bn_running, nbt, train, mfma_out, &f7, st)) return -1;
         ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
