@@ -387,12 +387,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
     char* gtile = stile + WG_KP * SPITCH;                    // [npix][GPITCH]
     // tile-independent staging table of the high-res patch: {relative element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
     int2* gtab = reinterpret_cast<int2*>(gtile + npix * GPITCH);
-    if constexpr (PRE) {
-        for (int it = tid; it < npix * GCH; it += 256) {
+    if constexpr (PRE) {   // (padded to MAXG*256 entries; padding entries carry image 0xffff, which never passes the batch test)
+        for (int it = tid; it < max(npix * GCH, MAXG * 256); it += 256) {
             const int pix = it / GCH, qq = it - pix * GCH;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
-            gtab[it] = make_int2(((img * Hg + py) * Wg + px) * CB + qq * E16,
-                                 ((pix * GPITCH + qq * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15));
+            gtab[it] = it < npix * GCH ? make_int2(((img * Hg + py) * Wg + px) * CB + qq * E16,
+                                                   ((pix * GPITCH + qq * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15))
+                                       : make_int2(0, 0xffff << 15);
         }
     }
 
@@ -438,35 +439,73 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
         const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         b0 = bt << a.lTB; y0 = ty << a.lth; x0 = tx << a.ltw;
     };
-    // prefetch registers; meta = LDS offset (19 bits) | pad flag (bit 19) | first channel (bits 20+), -1 = none
+    // prefetch registers.  A thread always stages the same 16-byte channel quarter of both operands (256 is a
+    // multiple of the chunks per pixel), so its coefficients live in registers; offsets are 32-bit bytes.
     Vec16<T> ps0[PRE ? WA : 1], ps1[(PRE && S_TWO) ? WA : 1], pg0[PRE ? MAXG : 1], pg1[(PRE && G_TWO) ? MAXG : 1];
-    int smeta[PRE ? WA : 1], gmeta[PRE ? MAXG : 1];
-    auto issue_tile = [&](int tile) {
+    int srel[PRE ? WA : 1], sloff[PRE ? WA : 1];     // low-res operand: tile-independent element offset / LDS offset | image << 20
+    int gmeta[PRE ? MAXG : 1];                        // high-res operand: table word of the chunk (LDS offset, halo flags, image)
+    constexpr int NE = Vec16<T>::N;
+    f32x2 ks0[PRE ? NE / 2 : 1], ks1[(PRE && S_TWO) ? NE / 2 : 1], ks2[PRE ? NE / 2 : 1];
+    f32x2 kg0[PRE ? NE / 2 : 1], kg1[(PRE && G_TWO) ? NE / 2 : 1], kg2[PRE ? NE / 2 : 1];
+    if constexpr (PRE) {
+        __syncthreads();   // coefficient rows / table published
+#pragma unroll
+        for (int u = 0; u < WA; ++u) {
+            const int it = tid + u * 256, k = it / SCH, qq = it - k * SCH;
+            const int img = k >> (a.lth + a.ltw), y = (k >> a.ltw) & (th - 1), x = k & (tw - 1);
+            srel[u] = ((img * Hs + y) * Ws + x) * CA + a0 + qq * E16;
+            sloff[u] = (k * SPITCH + qq * 16) | (img << 20);
+        }
+        const int sq = (tid % SCH) * E16, gq = (tid % GCH) * E16;
+#pragma unroll
+        for (int e = 0; e < NE / 2; ++e) {
+            ks0[e] = f32x2{cfs[sq + 2 * e], cfs[sq + 2 * e + 1]}; ks2[e] = f32x2{cfs[2 * 32 * WA + sq + 2 * e], cfs[2 * 32 * WA + sq + 2 * e + 1]};
+            if constexpr (S_TWO) ks1[e] = f32x2{cfs[32 * WA + sq + 2 * e], cfs[32 * WA + sq + 2 * e + 1]};
+            kg0[e] = f32x2{cfg[gq + 2 * e], cfg[gq + 2 * e + 1]}; kg2[e] = f32x2{cfg[2 * 32 * WB + gq + 2 * e], cfg[2 * 32 * WB + gq + 2 * e + 1]};
+            if constexpr (G_TWO) kg1[e] = f32x2{cfg[32 * WB + gq + 2 * e], cfg[32 * WB + gq + 2 * e + 1]};
+        }
+    }
+    // v0*k0 (+ v1*k1) + k2, LeakyReLU on the activation operand; pairs -> packed f32 math
+    auto xform2 = [&](const Vec16<T>& v0, const Vec16<T>& v1, const f32x2* k0, const f32x2* k1, const f32x2* k2, bool two, float slope)
+        __attribute__((always_inline)) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < NE / 2; ++e) {
+            const f32x2 x0 = {v0.get(2 * e), v0.get(2 * e + 1)};
+            f32x2 z;
+            if (two) {
+                const f32x2 x1 = {v1.get(2 * e), v1.get(2 * e + 1)};
+                z = x0 * k0[e] + (x1 * k1[e] + k2[e]);
+            } else {
+                z = x0 * k0[e] + k2[e];
+                const f32x2 zs = z * slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+            }
+            o.set(2 * e, z.x); o.set(2 * e + 1, z.y);
+        }
+        return o;
+    };
+    auto issue_tile = [&](int tile) __attribute__((always_inline)) {
         int b0, y0, x0; tile_origin(tile, b0, y0, x0);
+        const int sbase = ((b0 * Hs + y0) * Ws + x0) * CA;
 #pragma unroll
         for (int u = 0; u < (PRE ? WA : 0); ++u) {
-            bool ok; size_t g; int loff, cb;
-            s_map(b0, y0, x0, tid + u * 256, ok, g, loff, cb);
-            smeta[u] = loff | (ok ? 0 : 0x80000) | (cb << 20);
-            if (!ok) g = 0;
-            ps0[u] = *reinterpret_cast<const Vec16<T>*>(a.s0 + g);
-            if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(a.s1 + g);
+            const uint32_t g = (b0 + (sloff[u] >> 20)) < a.B ? (uint32_t)(sbase + srel[u]) * (uint32_t)sizeof(T) : 0u;
+            ps0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s0) + g);
+            if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s1) + g);
         }
-        const long gbase = (((long)b0 * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * CB + bc0;
+        const int gbase = ((b0 * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * CB + bc0;
+        const int tmask = (y0 == 0 ? 1 << 13 : 0) | (x0 == 0 ? 1 << 14 : 0), nb = a.B - b0;   // uniform per tile
+        int2 e[PRE ? MAXG : 1];
+#pragma unroll
+        for (int u = 0; u < (PRE ? MAXG : 0); ++u) e[u] = gtab[tid + u * 256];
 #pragma unroll
         for (int u = 0; u < (PRE ? MAXG : 0); ++u) {
-            const int it = tid + u * 256;
-            gmeta[u] = -1;
-            size_t g = 0;
-            if (it < npix * GCH) {
-                const int2 e = gtab[it];
-                const bool ok = ((b0 + (e.y >> 15)) < a.B) & !(((e.y >> 13) & 1) & (y0 == 0)) & !(((e.y >> 14) & 1) & (x0 == 0));
-                const int qq = it % GCH;
-                gmeta[u] = ((e.y & 0x1fff) << 4) | (ok ? 0 : 0x80000) | ((qq * E16) << 20);
-                if (ok) g = (size_t)(gbase + e.x);
-            }
-            pg0[u] = *reinterpret_cast<const Vec16<T>*>(a.g0 + g);
-            if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(a.g1 + g);
+            const bool ok = ((e[u].y & tmask) == 0) & ((e[u].y >> 15) < nb);
+            gmeta[u] = ok ? e[u].y : (e[u].y | (1 << 31));
+            const uint32_t g = ok ? (uint32_t)(gbase + e[u].x) * (uint32_t)sizeof(T) : 0u;
+            pg0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g0) + g);
+            if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g1) + g);
         }
     };
     if constexpr (PRE) { if (t_begin < t_end) issue_tile(t_begin); }
@@ -485,17 +524,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(Wg
             __syncthreads();                       // previous tile consumed
 #pragma unroll
             for (int u = 0; u < WA; ++u) {
-                Vec16<T> o = transform16<T>(ps0[u], ps1[S_TWO ? u : 0], S_TWO, cfs, 32 * WA, smeta[u] >> 20, a.sslope);
-                if (smeta[u] & 0x80000) o = zero_vec16<T>();
-                *reinterpret_cast<Vec16<T>*>(stile + (smeta[u] & 0x7ffff)) = o;
+                Vec16<T> o = xform2(ps0[u], ps1[S_TWO ? u : 0], ks0, ks1, ks2, S_TWO, a.sslope);
+                if ((b0 + (sloff[u] >> 20)) >= a.B) o = zero_vec16<T>();
+                *reinterpret_cast<Vec16<T>*>(stile + (sloff[u] & 0xfffff)) = o;
             }
 #pragma unroll
             for (int u = 0; u < MAXG; ++u) {
-                if (gmeta[u] >= 0) {
-                    Vec16<T> o = transform16<T>(pg0[u], pg1[G_TWO ? u : 0], G_TWO, cfg, 32 * WB, gmeta[u] >> 20, a.gslope);
-                    if (gmeta[u] & 0x80000) o = zero_vec16<T>();
-                    *reinterpret_cast<Vec16<T>*>(gtile + (gmeta[u] & 0x7ffff)) = o;
-                }
+                Vec16<T> o = xform2(pg0[u], pg1[G_TWO ? u : 0], kg0, kg1, kg2, G_TWO, a.gslope);
+                if (gmeta[u] < 0) o = zero_vec16<T>();
+                if (tid + u * 256 < npix * GCH) *reinterpret_cast<Vec16<T>*>(gtile + ((gmeta[u] & 0x1fff) << 4)) = o;
             }
             // patches with more than MAXG*256 chunks (many small images per tile): synchronous remainder
             for (int it = tid + MAXG * 256; it < npix * GCH; it += 256) {

@@ -386,7 +386,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const int WK = 4 / (WA * WB);
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16) +
-                       ((c->use_pipelined && sizeof(T) == 2 && !(WA == 2 && WB == 2)) ? (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16) * 8 : 0);   // + staging table (prefetching variants)
+                       ((c->use_pipelined && sizeof(T) == 2 && !(WA == 2 && WB == 2)) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)5 * WB * 256) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*256)
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
     {
