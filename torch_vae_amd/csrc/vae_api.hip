@@ -135,7 +135,7 @@ extern "C" void vae_destroy(vae_ctx* c) {
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
-static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 0;   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
+static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 1;   // tile 1: 64x32 channel tiles (prefetching kernel) also where 64x64 would fit   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
 static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out) {
     int WA, WB;
     if (CA >= 64 && CB >= 64 && g_wgrad_tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && g_wgrad_tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
