@@ -115,30 +115,68 @@ def main():
         dt = float(t.item())
     final_loss = losses.tolist()
 
-    # per-kernel durations (HIP events on the launch stream), outside the timed region
+    # per-kernel durations (HIP events on each launch stream), outside the timed region.  Weight gradients run on
+    # side streams concurrently with the input-gradient chain, so a launch's duration here (and in rocprofv3's
+    # trace of this same command) includes the time it shares the GPU; the roofline object therefore also carries
+    # the throughput of everything running inside the dominant launch's window, and the same launch measured
+    # alone (side streams off).
     roofline, kernels = None, []
     if rank == 0:
         L_ = _lib.lib()
-        _lib.check(L_.vae_profile(model._ctx.handle, 1), "vae_profile")
+        h = model._ctx.handle
         nprof = 3
-        for i in range(nprof):
-            step(args.warmup + args.steps + i)
-        buf = ctypes.create_string_buffer(1 << 16)
-        _lib.check(L_.vae_profile_report(model._ctx.handle, buf, len(buf)), "vae_profile_report")
-        if args.dump_order:
-            sbuf = ctypes.create_string_buffer(1 << 18)
-            _lib.check(L_.vae_profile_sequence(model._ctx.handle, sbuf, len(sbuf)), "vae_profile_sequence")
-            seq = json.loads(sbuf.value.decode())
+
+        def profile_steps():
+            _lib.check(L_.vae_profile(h, 1), "vae_profile")
+            for i in range(nprof):
+                step(args.warmup + args.steps + i)
+            buf = ctypes.create_string_buffer(1 << 16)
+            _lib.check(L_.vae_profile_report(h, buf, len(buf)), "vae_profile_report")
+            tbuf = ctypes.create_string_buffer(1 << 20)
+            _lib.check(L_.vae_profile_timeline(h, tbuf, len(tbuf)), "vae_profile_timeline")
+            seq = None
+            if args.dump_order:
+                sbuf = ctypes.create_string_buffer(1 << 18)
+                _lib.check(L_.vae_profile_sequence(h, sbuf, len(sbuf)), "vae_profile_sequence")
+                seq = json.loads(sbuf.value.decode())
+            _lib.check(L_.vae_profile(h, 0), "vae_profile")
+            ks = json.loads(buf.value.decode())
+            for k in ks:
+                k["ms_per_call"] = k["ms"] / k["calls"]
+                k["gbs"] = k["bytes"] / k["ms"] / 1e6 if k["ms"] > 0 else 0.0
+                k["tflops"] = k["flops"] / k["ms"] / 1e9 if k["ms"] > 0 else 0.0
+            ks.sort(key=lambda k: -k["ms"])
+            return ks, json.loads(tbuf.value.decode()), seq
+
+        kernels, timeline, seq = profile_steps()
+        if args.dump_order and seq is not None:
             json.dump(seq[:len(seq) // nprof], open(args.dump_order, "w"))
-        _lib.check(L_.vae_profile(model._ctx.handle, 0), "vae_profile")
-        kernels = json.loads(buf.value.decode())
-        for k in kernels:
-            k["ms_per_call"] = k["ms"] / k["calls"]
-            k["gbs"] = k["bytes"] / k["ms"] / 1e6 if k["ms"] > 0 else 0.0
-            k["tflops"] = k["flops"] / k["ms"] / 1e9 if k["ms"] > 0 else 0.0
-        kernels.sort(key=lambda k: -k["ms"])
         dom = kernels[0]
         ach = dom["gbs"]
+        # algorithmic bytes of every launch overlapping the dominant launch's windows / total window time
+        wbytes, wtime, mates = 0.0, 0.0, set()
+        for (n0, s0, e0, _b) in timeline:
+            if n0 != dom["name"]:
+                continue
+            wtime += e0 - s0
+            for (n1, s1, e1, b1) in timeline:
+                ov = min(e0, e1) - max(s0, s1)
+                if ov > 0 and e1 > s1:
+                    wbytes += b1 * ov / (e1 - s1)
+                    if n1 != n0 and b1 * ov / (e1 - s1) > 0.02 * dom["bytes"] / dom["calls"]:
+                        mates.add(n1)
+        window_gbs = wbytes / wtime / 1e6 if wtime > 0 else 0.0
+        # the same launch alone: side streams off for a few profiled steps
+        isolated = None
+        if not any(kv.startswith("use_side_stream=") for kv in args.set):
+            _lib.check(L_.vae_set_option(h, b"use_side_stream", 0), "vae_set_option")
+            step(0); torch.cuda.synchronize()
+            iso, _, _ = profile_steps()
+            _lib.check(L_.vae_set_option(h, b"use_side_stream", 1), "vae_set_option")
+            for k in iso:
+                if k["name"] == dom["name"]:
+                    isolated = {"avg_launch_us": round(1e3 * k["ms_per_call"], 2), "achieved": round(k["gbs"], 1),
+                                "frac": round(k["gbs"] / HBM_PEAK_GBS, 4)}
         # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
         # passes; tools/pmc_traffic.py writes profiles/pmc_traffic.json on the GPU box) - null when not collected
         traffic = None
@@ -153,12 +191,15 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom["name"],
                     "avg_launch_us": round(1e3 * dom["ms_per_call"], 2),
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
-                    "kernel_tflops": round(dom["tflops"], 1)}
+                    "kernel_tflops": round(dom["tflops"], 1),
+                    "concurrent_window": {"achieved": round(window_gbs, 1), "frac": round(window_gbs / HBM_PEAK_GBS, 4),
+                                          "with": sorted(mates)},
+                    "isolated": isolated}
         if args.kernels:
             tot = sum(k["ms"] for k in kernels) / nprof
-            print(f"per-step kernel time {tot:.3f} ms", file=sys.stderr)
+            print(f"per-step kernel time {tot:.3f} ms (sum over streams)", file=sys.stderr)
             for k in kernels:
-                print(f"  {k['name']:40s} calls/step {k['calls'] // nprof:3d}  {k['ms'] / nprof:8.3f} ms/step  {k['gbs']:8.1f} GB/s  {k['tflops']:7.1f} TF", file=sys.stderr)
+                print(f"  {k['name']:52s} calls/step {k['calls'] // nprof:3d}  {k['ms'] / nprof:8.3f} ms/step  {k['gbs']:8.1f} GB/s  {k['tflops']:7.1f} TF", file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -124,13 +124,28 @@ int vae_profile(vae_ctx* ctx, int enable);
 int vae_profile_report(vae_ctx* ctx, char* buf, int64_t capacity);
 /* JSON array of the labels of all profiled launches, in launch order. */
 int vae_profile_sequence(vae_ctx* ctx, char* buf, int64_t capacity);
+/* JSON array [[label, start_ms, end_ms, algorithmic_bytes], ...] of all profiled launches, times relative to
+ * the first one: weight gradients run on the context's side streams, so launches overlap. */
+int vae_profile_timeline(vae_ctx* ctx, char* buf, int64_t capacity);
+/* Diagnostics: per-wave phase cycle counters of the pipelined conv kernel of one layer.  tag = layer label
+ * ("final_layer.0" ...), epi = epilogue kind (0 forward, 1 backward, 2 plain; +16 selects the transposed-conv
+ * kernel), out = device buffer of grid*4*6 int64 (NULL switches it off). */
+int vae_debug_stamps(vae_ctx* ctx, const char* tag, int epi, long long* out);
 
 /* Debug / test hooks: copy an internal NHWC tensor to f32 NCHW.  which: 0..7 raw conv output
  * of BN layer i, 8..15 its dz, 16 decoder_input output, 17 its gradient. */
 int vae_debug_tensor(vae_ctx* ctx, int which, float* out, int64_t capacity, vae_stream_t stream);
 /* hardware self-test of the transposed LDS read used by the bf16 weight-gradient kernel */
 int vae_selftest_tr16(vae_stream_t stream);
-/* 0/1: use ds_read_b64_tr_b16 in the bf16 weight-gradient kernel (default 1) */
+/* Tuning / diagnostic switches (defaults in brackets):
+ *   use_tr16 [1]            ds_read_b64_tr_b16 in the bf16 weight-gradient kernel
+ *   use_mfma_convout [1]    MFMA versions of the output-conv kernels (bf16)
+ *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
+ *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
+ *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
+ *   knob_wave_nt_max [1]    wave-independent tiles for output tiles of up to this many 32-channel blocks
+ *   knob_nt_max [4], knob_up_per_cu [4], knob_convout_grid [2048], knob_pipe_max_cout [256], knob_bwd_per_cu [0],
+ *   knob_wgrad_tile [1], knob_wgrad_wgs [1024], knob_wgrad_cap_mb [48], knob_ablate_b [0]   grid / tile sizing */
 int vae_set_option(vae_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

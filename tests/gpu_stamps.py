@@ -9,7 +9,7 @@ H, L, B = 128, 16, 256
 model = VanillaVAE(1, L, H, generalised=True, compute_dtype="bf16", max_batch=B).cuda()
 x = SyntheticPianorollLoader(B, H, 1, device="cuda").batch(0)[0]
 model.fused_forward_backward(x)
-Lb = _lib.lib(); Lb.vae_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+Lb = _lib.lib()
 for k, v in (json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}).items():
     assert Lb.vae_set_option(model._ctx.handle, k.encode(), v) == 0
 names = ["barrierA", "write_patch", "barrierB", "issue", "mfma", "epilogue"]

@@ -20,8 +20,7 @@ torch.cuda.synchronize()
 Lb.vae_profile(model._ctx.handle, 1)
 model.fused_forward_backward(x); opt.step()
 buf = ctypes.create_string_buffer(1 << 18)
-Lb.vae_profile_timeline.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
 assert Lb.vae_profile_timeline(model._ctx.handle, buf, len(buf)) == 0
 Lb.vae_profile(model._ctx.handle, 0)
-for name, t0, t1 in sorted(json.loads(buf.value.decode()), key=lambda r: r[1]):
+for name, t0, t1, _bytes in sorted(json.loads(buf.value.decode()), key=lambda r: r[1]):
     print(f"{1e3*t0:8.1f} {1e3*t1:8.1f} {1e3*(t1-t0):7.1f} us  {name}")

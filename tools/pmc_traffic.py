@@ -13,7 +13,7 @@ import csv, glob, json, os, re, sys, collections
 
 
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
@@ -23,7 +23,8 @@ def load(d, counter):
 KERNEL_OF = [("down_", r"(?<![a-z_])down2?_kernel"), ("up_", r"(?<![a-z_])up2?_kernel"), ("wgrad_kernel", r"(?<![a-z_])wgrad_kernel"),
              ("convout_fwd", r"convout_fwd"), ("convout_bwd", r"convout_bwd"), ("conv1_fwd", r"conv1_fwd"),
              ("conv1_wgrad", r"conv1_wgrad"), ("dense", r"dense_kernel"), ("decin_fwd", r"decin_fwd"),
-             ("decin_wgrad", r"decin_wgrad"), ("fc_wgrad", r"fc_wgrad"), ("fc_dgrad", r"fc_dgrad"), ("pack_weights", r"pack_kernel")]
+             ("decin_wgrad", r"decin_wgrad"), ("fc_wgrad", r"fc_wgrad"), ("fc_dgrad", r"fc_dgrad"), ("pack_weights", r"pack_kernel"),
+             ("reduce_slab", r"reduce_slab_kernel"), ("bn_", r"bn_finalize_kernel")]
 
 
 def regex_of(label):

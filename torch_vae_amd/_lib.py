@@ -70,6 +70,8 @@ def lib():
     _sig(L.vae_profile, i32, [p, i32])
     _sig(L.vae_profile_report, i32, [p, C.c_char_p, i64])
     _sig(L.vae_profile_sequence, i32, [p, C.c_char_p, i64])
+    _sig(L.vae_profile_timeline, i32, [p, C.c_char_p, i64])
+    _sig(L.vae_debug_stamps, i32, [p, C.c_char_p, i32, p])
     _sig(L.vae_debug_tensor, i32, [p, i32, p, i64, p])
     _sig(L.vae_selftest_tr16, i32, [p])
     _sig(L.vae_set_option, i32, [p, C.c_char_p, i32])
@@ -81,7 +83,7 @@ EXPORTS = [
     "vae_last_error", "vae_abi_version", "vae_param_layout", "vae_bn_layout", "vae_create", "vae_destroy",
     "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_elbo_generic",
     "vae_backward", "vae_adamw_step", "vae_train_step", "vae_synth_pianoroll", "vae_profile",
-    "vae_profile_report", "vae_profile_sequence", "vae_debug_tensor",
+    "vae_profile_report", "vae_profile_sequence", "vae_profile_timeline", "vae_debug_stamps", "vae_debug_tensor",
     "vae_selftest_tr16", "vae_set_option",
 ]
 

@@ -746,7 +746,7 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     {
         SideFork f = fork_side(c, st, 0);   // the kernel above wrote its partial sums into side stream 0's slab
         if (f.rc) return f.rc;
-        if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st)) return -1;
+        if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st, c)) return -1;
         hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39], 1, 1.f);
         LAUNCH_CHECK("d2f_kernel");
     }
@@ -787,11 +787,13 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
             if (f.rc) return f.rc;
             float* sw = f.slab; float* sb = f.slab + (size_t)nz * c->F * L;
             dim3 grid((unsigned)(c->F / 256), (L + 31) / 32, nz);
-            ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, f.st);
-            hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, f.st, reinterpret_cast<const T*>(c->dd0), c->z, sw, sb, B, (int)c->F, L, c->s2, bsplit);
-            LAUNCH_CHECK("decin_wgrad_kernel");
-            if (launch_reduce(sw, nz, (size_t)c->F * L, grads + c->poff[20], 0, 0, f.st)) return -1;
-            if (launch_reduce(sb, nz, (size_t)c->F, grads + c->poff[21], 0, 0, f.st)) return -1;
+            {
+                ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, f.st);
+                hipLaunchKernelGGL((decin_wgrad_kernel<T>), grid, dim3(256), 0, f.st, reinterpret_cast<const T*>(c->dd0), c->z, sw, sb, B, (int)c->F, L, c->s2, bsplit);
+                LAUNCH_CHECK("decin_wgrad_kernel");
+            }
+            if (launch_reduce(sw, nz, (size_t)c->F * L, grads + c->poff[20], 0, 0, f.st, c)) return -1;
+            if (launch_reduce(sb, nz, (size_t)c->F, grads + c->poff[21], 0, 0, f.st, c)) return -1;
         }
         DenseArgs<T> a; memset(&a, 0, sizeof(a));
         a.A = reinterpret_cast<const T*>(c->dd0); a.coef = nullptr; a.slope = 1.f; a.C = 256;
@@ -820,11 +822,13 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
             if (f.rc) return f.rc;
             float* smu = f.slab; float* svar = f.slab + (size_t)nz * L * c->F;
             w.dwmu = smu; w.dwvar = svar;
-            ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
-            hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, f.st, w);
-            LAUNCH_CHECK("fc_wgrad_kernel");
-            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, f.st)) return -1;
-            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, f.st)) return -1;
+            {
+                ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
+                hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, f.st, w);
+                LAUNCH_CHECK("fc_wgrad_kernel");
+            }
+            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, f.st, c)) return -1;
+            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, f.st, c)) return -1;
         }
         FcDgradArgs<T> d;
         d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
@@ -861,11 +865,13 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
         SideFork f = fork_side(c, st);
         if (f.rc) return f.rc;
-        ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, f.st);
-        hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, f.st, x, reinterpret_cast<const T*>(c->lay[0].dz),
-                           reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, f.slab, B, H, H);
-        LAUNCH_CHECK("conv1_wgrad_kernel");
-        if (launch_reduce(f.slab, grid, 288, grads + c->poff[0], 32, 1, f.st)) return -1;
+        {
+            ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, f.st);
+            hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, f.st, x, reinterpret_cast<const T*>(c->lay[0].dz),
+                               reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, f.slab, B, H, H);
+            LAUNCH_CHECK("conv1_wgrad_kernel");
+        }
+        if (launch_reduce(f.slab, grid, 288, grads + c->poff[0], 32, 1, f.st, c)) return -1;
     }
     return join_sides(c, st);
 }
@@ -1006,7 +1012,7 @@ extern "C" int vae_profile_sequence(vae_ctx* c, char* buf, int64_t cap) {
     return 0;
 }
 
-// JSON: [[name, start_ms, end_ms], ...] relative to the first recorded launch (shows the overlap of the two streams)
+// JSON: [[name, start_ms, end_ms, algorithmic_bytes], ...] relative to the first recorded launch (shows the overlap of the streams)
 extern "C" int vae_profile_timeline(vae_ctx* c, char* buf, int64_t cap) {
     if (!c) return vae_set_error("vae_profile_timeline", "null ctx");
     HIP_CHECK_RET(hipDeviceSynchronize());
@@ -1015,7 +1021,7 @@ extern "C" int vae_profile_timeline(vae_ctx* c, char* buf, int64_t cap) {
         float t0 = 0.f, t1 = 0.f;
         (void)hipEventElapsedTime(&t0, c->prof_recs[0].e0, c->prof_recs[i].e0);
         (void)hipEventElapsedTime(&t1, c->prof_recs[0].e0, c->prof_recs[i].e1);
-        char tmp[64]; snprintf(tmp, sizeof(tmp), "\",%.4f,%.4f]", t0, t1);
+        char tmp[96]; snprintf(tmp, sizeof(tmp), "\",%.4f,%.4f,%.0f]", t0, t1, c->prof_recs[i].bytes);
         out += std::string(i ? ",[\"" : "[\"") + c->prof_recs[i].name + tmp;
     }
     out += "]";
