@@ -9,10 +9,15 @@
  * Conventions: plain pointers and sizes, no torch types.  All tensor memory
  * (parameters, gradients, optimiser state, inputs, outputs) is owned by the caller
  * (PyTorch's allocator) and borrowed for the call; only scratch is owned by the
- * context.  Every launch goes to the explicit hipStream_t (pass
- * torch.cuda.current_stream().cuda_stream).  Functions return 0 on success or a
- * negative code, with the message in vae_last_error().  A context is not
- * re-entrant; use one per process / GPU.
+ * context.  Work is ordered on the explicit hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream): results of a call are visible to later
+ * work on that stream, and a call sees everything enqueued on it before.  Inside
+ * vae_forward / vae_backward the context also uses non-blocking side streams of its own
+ * (weight packing, weight gradients); they are forked from and joined back into the
+ * caller's stream with HIP events before the call returns, so the caller never has to
+ * synchronise with them (and the calls can be captured in a hipGraph).  Functions return
+ * 0 on success or a negative code, with the message in vae_last_error().  A context is
+ * not re-entrant; use one per process / GPU.
  */
 #ifndef VAE_STEP_H
 #define VAE_STEP_H
