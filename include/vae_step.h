@@ -148,7 +148,7 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
  *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
  *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
- *   knob_wave_nt_max [1]    wave-independent tiles for output tiles of up to this many 32-channel blocks
+ *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks
  *   knob_nt_max [4], knob_up_per_cu [4], knob_convout_grid [2048], knob_pipe_max_cout [256], knob_bwd_per_cu [0],
  *   knob_wgrad_tile [1], knob_wgrad_wgs [1024], knob_wgrad_cap_mb [48], knob_ablate_b [0]   grid / tile sizing */
 int vae_set_option(vae_ctx* ctx, const char* name, int value);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
     }
-    constexpr int UNR = 2;   // pixels per thread per trip, all loads issued before use (latency-bound loop)
+    constexpr int UNR = 4;   // pixels per thread per trip, all loads issued before use (latency-bound loop)
     for (int q0 = blockIdx.x * 64 + slot; q0 < P; q0 += gridDim.x * 64 * UNR) {
         float xv[UNR][9], dv[UNR][8], yv[UNR][8];
 #pragma unroll
