@@ -240,8 +240,14 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) { issue(cur, 0); if (EPI == EPI_BWD) issue_y(cur); }
+#ifdef VAE_PHASE_STAMPS
     long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
+#endif
+#ifdef VAE_PHASE_STAMPS   // diagnostic build (make STAMPS=1): the stamps split the loop body into scheduling regions
 #define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
+#else
+#define STAMP(k)
+#endif
     while (have) {
         if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A) previous item fully consumed
         STAMP(0)
@@ -334,7 +340,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         STAMP(5)
         pi = npi; chunk = nchunk; cur = nxt; have = nhave;
     }
+#ifdef VAE_PHASE_STAMPS
     if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
+#endif
 #undef STAMP
 
     if constexpr (EPI != EPI_PLAIN) {
@@ -541,8 +549,14 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) issue(cur, 0);
+#ifdef VAE_PHASE_STAMPS
     long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
+#endif
+#ifdef VAE_PHASE_STAMPS   // diagnostic build (make STAMPS=1): the stamps split the loop body into scheduling regions
 #define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
+#else
+#define STAMP(k)
+#endif
     while (have) {
         if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A)
         STAMP(0)
@@ -631,7 +645,9 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         STAMP(5)
         pi = npi; chunk = nchunk; cur = nxt; have = nhave;
     }
+#ifdef VAE_PHASE_STAMPS
     if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
+#endif
 #undef STAMP
 
     if constexpr (EPI != EPI_PLAIN) {
