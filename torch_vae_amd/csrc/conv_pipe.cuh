@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         const int c0 = chunk * CK;
         {
             // weights straight from L1/L2 as the B operand, kept two taps ahead of the matrix pipe
-            constexpr int DEPTH = (NT <= 2 ? 4 : 2);   // taps of weight fragments in flight
+            constexpr int DEPTH = 4;   // taps of weight fragments in flight (L2 latency ~ 3 tap steps of MFMA work)
             Frag<T> bq[DEPTH][KS][NT];
             auto load_b = [&](int t, int slot) {
 #pragma unroll
