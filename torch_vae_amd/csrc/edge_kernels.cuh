@@ -670,23 +670,25 @@ template <typename T>
 __global__ void pack_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     T* dst = reinterpret_cast<T*>(d.dst);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long)gridDim.x * blockDim.x) {
+    // 32-bit index arithmetic (every image is far below 2^31 elements): the 64-bit divisions dominated this kernel
+    const int total = (int)d.n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (d.kind == 0) {
             const int K = d.k_is_first ? d.A : d.Bc, N = d.k_is_first ? d.Bc : d.A;
-            const int e = i & 7; long r = i >> 3; const int n = r % N; r /= N; const int kg = r % (K >> 3); const int t = r / (K >> 3);
+            const int e = i & 7; int r = i >> 3; const int n = r % N; r /= N; const int kg = r % (K >> 3); const int t = r / (K >> 3);
             const int k = kg * 8 + e;
             const int ai = d.k_is_first ? k : n, bi = d.k_is_first ? n : k;
-            dst[i] = fromfloat<T>(d.src[((long)ai * d.Bc + bi) * 9 + t]);
+            dst[i] = fromfloat<T>(d.src[(ai * d.Bc + bi) * 9 + t]);
         } else if (d.kind == 1) {
-            const int e = i & 7; long r = i >> 3; const int n = r % d.npad; const long fp = (r / d.npad) * 8 + e;
-            const long F = (long)256 * d.s2; const long fr = (fp & 255) * d.s2 + (fp >> 8);
+            const int e = i & 7; const int r = i >> 3; const int n = r % d.npad; const int fp = (r / d.npad) * 8 + e;
+            const int F = 256 * d.s2; const int fr = (fp & 255) * d.s2 + (fp >> 8);
             float v = 0.f;
             if (n < d.L) v = d.src[(long)n * F + fr]; else if (n < 2 * d.L) v = d.src2[(long)(n - d.L) * F + fr];
             dst[i] = fromfloat<T>(v);
         } else if (d.kind == 2) {
-            const int e = i & 7; long r = i >> 3; const int n = r % d.npad; const long fp = (r / d.npad) * 8 + e;
-            const long fr = (fp & 255) * d.s2 + (fp >> 8);
-            dst[i] = fromfloat<T>(n < d.L ? d.src[fr * d.L + n] : 0.f);
+            const int e = i & 7; const int r = i >> 3; const int n = r % d.npad; const int fp = (r / d.npad) * 8 + e;
+            const int fr = (fp & 255) * d.s2 + (fp >> 8);
+            dst[i] = fromfloat<T>(n < d.L ? d.src[(long)fr * d.L + n] : 0.f);
         } else {
             const int t = i / d.A, c = i % d.A;   // dst f32 [9][C] from src [C][9]
             reinterpret_cast<float*>(d.dst)[i] = d.src[c * 9 + t];

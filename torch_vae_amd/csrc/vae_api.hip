@@ -93,7 +93,7 @@ struct vae_ctx {
     // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, use_fused_bn;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, use_fused_bn, bwd_dirty;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -160,7 +160,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
     c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
-    c->packed_for = nullptr; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
+    c->packed_for = nullptr; c->bwd_dirty = 1; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
     if (maxB < 1) { vae_set_error("vae_create", "max_batch < 1"); delete c; return nullptr; }
@@ -509,7 +509,7 @@ static int pack_weights(vae_ctx* c, const float* params, hipStream_t st) {
         c->packed_for = params;
     }
     ProfScope ps(c, "pack_weights", 0, 0, st);
-    hipLaunchKernelGGL((pack_kernel<T>), dim3(64, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
+    hipLaunchKernelGGL((pack_kernel<T>), dim3(128, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
     LAUNCH_CHECK("pack_kernel");
     return 0;
 }
@@ -640,7 +640,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
                         const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, hipStream_t st) {
     const int H = c->H, L = c->L;
     c->B = B; c->trained = train; c->x = x; c->xhat = xhat; c->mu = mu; c->lv = lv; c->z = z;
-    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st)); c->bwd_dirty = 0;
     static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // encoder block 0 (reads the raw f32 weights); the MFMA layers' packed weight images are built meanwhile
     c->tag = kLayerTag[0];
@@ -708,8 +708,11 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     const int B = c->B, H = c->H, L = c->L;
     size_t nfwd = 0;
     for (int i = 0; i < 8; ++i) nfwd += 2 * kBnC[i];
-    HIP_CHECK_RET(hipMemsetAsync(c->dstats + nfwd, 0, nfwd * sizeof(double), st));   // stat_b
-    HIP_CHECK_RET(hipMemsetAsync(c->accum + 2, 0, sizeof(double), st));
+    if (c->bwd_dirty) {   // (the forward zeroed every accumulator; only a repeated backward has to clear its own)
+        HIP_CHECK_RET(hipMemsetAsync(c->dstats + nfwd, 0, nfwd * sizeof(double), st));   // stat_b
+        HIP_CHECK_RET(hipMemsetAsync(c->accum + 2, 0, sizeof(double), st));
+    }
+    c->bwd_dirty = 1;
     const float* dl_src = c->dlogit; const float* dl_scale = gscale;
     if (g_xhat || !add_kl) {
         // explicit upstream gradient on xhat (plus, when add_kl, the fused standard-ELBO term)
@@ -863,8 +866,8 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (bn_finalize_now(c, make_fuse_bwd(c, 0, params, grads), st)) return -1;
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
-        SideFork f = fork_side(c, st);
-        if (f.rc) return f.rc;
+        // last link of the chain: stays on the caller's stream (a side stream would only add an event round trip)
+        SideFork f{st, c->slab, 0};
         {
             ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, f.st);
             hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, f.st, x, reinterpret_cast<const T*>(c->lay[0].dz),
@@ -894,7 +897,7 @@ extern "C" int vae_decode(vae_ctx* c, const float* z, int B, const float* params
     if (!z || !params || !xhat) return vae_set_error("vae_decode", "null tensor pointer");
     hipStream_t st = (hipStream_t)stream;
     c->B = B; c->trained = 0;   // a decode-only pass cannot be differentiated
-    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st));
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st)); c->bwd_dirty = 0;
     int rc = c->dtype == VAE_DTYPE_BF16 ? pack_weights<bf16>(c, params, st) : pack_weights<float>(c, params, st);
     if (rc) return rc;
     // the reconstruction-loss side outputs of the output-conv kernel are unused here: xhat doubles as the target
