@@ -386,3 +386,82 @@ def test_decode_sample_evaluate_and_checkpoint(tmp_path):
         mm.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
         oo.step()
     assert rel_l2(m2.flat_parameters().cpu().numpy(), m.flat_parameters().cpu().numpy()) < 1e-6
+
+
+def test_c_abi_train_step_matches_python_path():
+    """vae_train_step (forward + loss + backward + AdamW in one C call, train.py:634-659) against the same steps
+    driven from Python (fused_forward_backward + FusedAdamW.step)."""
+    import ctypes as C
+    from torch_vae_amd import _lib
+    from torch_vae_amd.optim import FusedAdamW
+    H, L, B, gen, K = 32, 16, 8, False, 3
+    p = perturbed_params(L, H, 11, gen)
+    xs = [torch.from_numpy(vo.synth_pianoroll(B, H, 50 + i)).cuda() for i in range(K)]
+    es = [torch.from_numpy(vo.counter_normal(B * L, 50 + i, 5).reshape(B, L)).float().cuda() for i in range(K)]
+    lr, b1, b2, aeps, wd = 3e-3, 0.9, 0.999, 1e-8, 0.01
+    # Python path
+    m1 = make_model(H, L, gen, "f32", p)
+    opt = FusedAdamW([{"params": list(m1.encoder.parameters())}, {"params": list(m1.decoder.parameters())}],
+                     lr=lr, betas=(b1, b2), eps=aeps, weight_decay=wd)
+    losses1 = []
+    for i in range(K):
+        out3, _ = m1.fused_forward_backward(xs[i], eps=es[i])
+        opt.step()
+        losses1.append(out3.tolist())
+    # one C call per step on a second model's buffers
+    m2 = make_model(H, L, gen, "f32", p)
+    ctx = m2._context(B)
+    flat, g = m2.flat_parameters(), m2.flat_grads()
+    mom, var = torch.zeros_like(flat), torch.zeros_like(flat)
+    opt._bind()
+    offs = (C.c_int64 * 2)(*[r[0] for r in opt._ranges]); sizes = (C.c_int64 * 2)(*[r[1] for r in opt._ranges])
+    lrs = (C.c_float * 2)(lr, lr); b1s = (C.c_float * 2)(b1, b1)
+    xhat = torch.empty(B, 1, H, H, device="cuda"); mu = torch.empty(B, L, device="cuda"); lv = torch.empty_like(mu); z = torch.empty_like(mu)
+    out3 = torch.empty(3, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    losses2 = []
+    for i in range(K):
+        _lib.check(_lib.lib().vae_train_step(ctx.handle, xs[i].data_ptr(), B, flat.data_ptr(), g.data_ptr(), mom.data_ptr(), var.data_ptr(),
+                                             m2._bnflat.data_ptr(), m2._nbt.data_ptr(), es[i].data_ptr(), 0, 1.0, 2, offs, sizes, lrs, b1s,
+                                             b2, aeps, wd, i + 1, xhat.data_ptr(), mu.data_ptr(), lv.data_ptr(), z.data_ptr(),
+                                             out3.data_ptr(), st), "vae_train_step")
+        losses2.append(out3.tolist())
+    np.testing.assert_allclose(losses2, losses1, rtol=1e-6)
+    np.testing.assert_array_equal(flat.cpu().numpy(), m1.flat_parameters().detach().cpu().numpy())
+    np.testing.assert_array_equal(m2._bnflat.cpu().numpy(), m1._bnflat.cpu().numpy())
+    assert m2._nbt.tolist() == m1._nbt.tolist() == [K] * 8
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_execution_options_do_not_change_results(dtype):
+    """Side streams and the folded BatchNorm finalisation only change WHERE work runs: results are bit-identical.
+    Wave-independent vs workgroup tiles change the order BatchNorm statistics are summed in: rounding-level agreement."""
+    from torch_vae_amd import _lib
+    H, L, B, gen = 64, 16, 6, True
+    p = perturbed_params(L, H, 21, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 31)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 31, 5).reshape(B, L)).float().cuda()
+
+    def run(opts):
+        model = make_model(H, L, gen, dtype, p)
+        model._context(B)
+        for k, v in opts.items():
+            assert _lib.lib().vae_set_option(model._ctx.handle, k.encode(), v) == 0
+        res = []
+        for _ in range(2):   # twice: the second pass also exercises re-use of the side streams / slabs
+            out3, xhat = model.fused_forward_backward(x, eps=eps)
+            res.append((out3.cpu().numpy().copy(), xhat.cpu().numpy().copy(), model.flat_grads().detach().cpu().numpy().copy(),
+                        model._bnflat.cpu().numpy().copy()))
+        return res
+
+    base = run({})
+    for opts in ({"use_side_stream": 0}, {"use_fused_bn": 0}, {"use_side_stream": 0, "use_fused_bn": 0}):
+        got = run(opts)
+        for a, b in zip(got, base):
+            for u, v in zip(a, b):
+                np.testing.assert_array_equal(u, v, err_msg=str(opts))
+    got = run({"knob_wave_nt_max": 0})
+    for a, b in zip(got, base):
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-6 if dtype == "f32" else 3e-4)
+        assert rel_l2(a[1], b[1]) < (1e-5 if dtype == "f32" else 3e-3)
+        assert rel_l2(a[2], b[2]) < (5e-3 if dtype == "f32" else 5e-2)
