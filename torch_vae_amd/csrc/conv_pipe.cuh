@@ -68,15 +68,23 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 // processed in order), so the 8 waves of a CU sit in different phases and cover each other's stalls.
 // EPI is a template parameter (the per-element epilogue is straight-line code); forward launches stage one source
 // tensor with BatchNorm+LeakyReLU, backward launches (EPI_BWD / EPI_PLAIN) stage the two-source gradient operand.
-template <typename T, int NT, int EPI, bool WV>
+// LAY = 1 (workgroup tiles only, even NT): the 4 waves form a 2x2 grid over the 128-pixel x 32*NT-channel tile,
+// each computing 64 pixels x 16*NT channels, so every weight fragment a wave loads feeds two MFMAs - half the
+// weight traffic through the vector-memory pipe, which is what bounds the deep layers (wide N, few pixels).
+template <typename T, int NT, int EPI, bool WV, int LAY = 0>
 __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr bool TWO_SRC = EPI != EPI_FWD;
+    constexpr bool W22 = LAY == 1;
+    static_assert(!W22 || (!WV && NT % 2 == 0), "2x2 wave layout: workgroup tiles, even NT");
+    constexpr int MTW = W22 ? 2 : 1, NTW = W22 ? NT / 2 : NT, OROWS = 32 * MTW;   // per wave: M sub-tiles, N sub-tiles, out-tile rows
     constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 10;
-    constexpr int OROW = 32 * NT * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;   // out-tile row bytes / chunks
-    constexpr int OPL = OCH / 2;                                                     // out chunks per lane (32 px per wave)
+    constexpr int OROW = 32 * NTW * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;  // out-tile row bytes / chunks
+    constexpr int OPL = OROWS * OCH / 64;                                            // out chunks per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
+    const int wm = W22 ? (wave & 1) : wv0, wn = W22 ? (wave >> 1) : 0;   // wave coordinates in the workgroup tile
+    const int mrow0 = wm * OROWS;                                         // first tile pixel of this wave
     constexpr int SSTR = WV ? 64 : 256;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP, nitems = npix * 4;
@@ -85,8 +93,8 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     char* patch0 = smem + ((3 * Cin * 4 + 15) & ~15);
     char* patch = patch0 + (WV ? wave * npix * PATCH_PITCH : 0);
     char* otile = patch0 + (WV ? 4 : 1) * npix * PATCH_PITCH;                 // [4 waves][32 px][OPITCH]
-    float* red = reinterpret_cast<float*>(otile + 128 * OPITCH);
-    char* mytile = otile + wave * 32 * OPITCH;
+    float* red = reinterpret_cast<float*>(otile + 4 * OROWS * OPITCH);
+    char* mytile = otile + wave * OROWS * OPITCH;
     // per-item staging table (tile-independent): {relative global element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
     int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
     // (padded to MAXI*SSTR entries; padding entries carry image 0xffff, which never passes the batch test)
@@ -104,16 +112,20 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
     }
 
-    const int R = wv0 * 32 + r;
-    const int pbase = ((R >> (a.lth + a.ltw)) * PH + 2 * ((R >> a.ltw) & (th - 1))) * PW + 2 * (R & (tw - 1));
+    int pbase[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int R = mrow0 + mt * 32 + r;
+        pbase[mt] = ((R >> (a.lth + a.ltw)) * PH + 2 * ((R >> a.ltw) & (th - 1))) * PW + 2 * (R & (tw - 1));
+    }
 
     // one N tile per workgroup for its whole life: epilogue coefficients live in registers; the forward
     // accumulators start from the conv bias
-    float ebv[NT], esc[NT], esh[NT], eis[NT], exm[NT];
+    float ebv[NTW], esc[NTW], esh[NTW], eis[NTW], exm[NTW];
     {
-        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT;
+        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT + wn * NTW * 32;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int n = n0w + nt * 32 + r;
             ebv[nt] = (EPI == EPI_FWD && a.bias) ? a.bias[n] : 0.f;
             esc[nt] = esh[nt] = eis[nt] = exm[nt] = 0.f;
@@ -123,13 +135,15 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             }
         }
     }
-    f32x16 acc[NT];
-    f32x2 s1[NT], s2[NT];
+    f32x16 acc[MTW][NTW];
+    f32x2 s1[NTW], s2[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
         s1[nt] = f32x2{0.f, 0.f}; s2[nt] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = ebv[nt];
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = ebv[nt];
     }
 
     // a thread always stages the same 16-byte quarter of a pixel (stid & 3): its per-channel coefficients live in
@@ -213,9 +227,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     int orel[OPL], opk[OPL];
 #pragma unroll
     for (int u = 0; u < OPL; ++u) {
-        const int id = lane + 64 * u, row = id / OCH, qq = id - row * OCH, RR = wv0 * 32 + row;
+        const int id = lane + 64 * u, row = id / OCH, qq = id - row * OCH, RR = mrow0 + row;
         const int img = RR >> (a.lth + a.ltw), ty = (RR >> a.ltw) & (th - 1), tx = RR & (tw - 1);
-        orel[u] = ((img * a.Hs + ty) * a.Ws + tx) * Cout + qq * E16;
+        orel[u] = ((img * a.Hs + ty) * a.Ws + tx) * Cout + wn * NTW * 32 + qq * E16;
         opk[u] = (row * OPITCH + qq * 16) | (img << 20);
     }
     // global element offset of out-tile chunk u, or -1 (image beyond the batch)
@@ -274,33 +288,38 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         {
             // weights straight from L1/L2 as the B operand, kept two taps ahead of the matrix pipe
             constexpr int DEPTH = 4;   // taps of weight fragments in flight (L2 latency ~ 3 tap steps of MFMA work)
-            Frag<T> bq[DEPTH][KS][NT];
+            Frag<T> bq[DEPTH][KS][NTW];
             auto load_b = [&](int t, int slot) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const uint32_t kg = (uint32_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq[slot][ks][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + nt * 32 + r) * (uint32_t)(8 * sizeof(T))));
+                    for (int nt = 0; nt < NTW; ++nt) bq[slot][ks][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + (wn * NTW + nt) * 32 + r) * (uint32_t)(8 * sizeof(T))));
                 }
             };
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) load_b(d, d);
             // A fragments one (tap, k-step) ahead of the matrix pipe
-            auto load_a = [&](int step) __attribute__((always_inline)) {
+            auto load_a = [&](int step, int mt) __attribute__((always_inline)) {
                 const int t = step / KS, ks = step % KS;
-                return load_frag(reinterpret_cast<const T*>(patch + (pbase + (t / 3) * PW + (t % 3)) * PATCH_PITCH + ks * 32) + h * 8);
+                return load_frag(reinterpret_cast<const T*>(patch + (pbase[mt] + (t / 3) * PW + (t % 3)) * PATCH_PITCH + ks * 32) + h * 8);
             };
-            Frag<T> af = load_a(0);
+            Frag<T> af[MTW], afn[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) af[mt] = load_a(0, mt);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int step = t * KS + ks;
-                    Frag<T> afn = af;
-                    if (step + 1 < 9 * KS) afn = load_a(step + 1);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma(acc[nt], af, bq[t % DEPTH][ks][nt]);
-                    af = afn;
+                    for (int mt = 0; mt < MTW; ++mt) { afn[mt] = af[mt]; if (step + 1 < 9 * KS) afn[mt] = load_a(step + 1, mt); }
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) mma(acc[mt][nt], af[mt], bq[t % DEPTH][ks][nt]);
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) af[mt] = afn[mt];
                 }
                 if (t + DEPTH < 9 && !(a.two_src & 2)) load_b(t + DEPTH, t % DEPTH);
             }
@@ -314,17 +333,20 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             // statistics skip them through the checked variant, chosen once per tile.
             auto epi_body = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+                for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const int row0 = acc_row(i, lane), row1 = acc_row(i + 1, lane);
-                        T* c0 = reinterpret_cast<T*>(mytile + row0 * OPITCH) + nt * 32 + r;
-                        T* c1 = reinterpret_cast<T*>(mytile + row1 * OPITCH) + nt * 32 + r;
-                        constexpr bool CK_ = decltype(checked)::value;
-                        const bool ok0 = !CK_ || (cur.b0 + ((wv0 * 32 + row0) >> (a.lth + a.ltw))) < a.B;
-                        const bool ok1 = !CK_ || (cur.b0 + ((wv0 * 32 + row1) >> (a.lth + a.ltw))) < a.B;
-                        epi_pair<T, EPI, CK_>(acc[nt][i], acc[nt][i + 1], c0, c1, ok0, ok1, esc[nt], esh[nt], a.oslope, s1[nt], s2[nt]);
-                        acc[nt][i] = ebv[nt]; acc[nt][i + 1] = ebv[nt];
+                    for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const int row0 = mt * 32 + acc_row(i, lane), row1 = mt * 32 + acc_row(i + 1, lane);
+                            T* c0 = reinterpret_cast<T*>(mytile + row0 * OPITCH) + nt * 32 + r;
+                            T* c1 = reinterpret_cast<T*>(mytile + row1 * OPITCH) + nt * 32 + r;
+                            constexpr bool CK_ = decltype(checked)::value;
+                            const bool ok0 = !CK_ || (cur.b0 + ((mrow0 + row0) >> (a.lth + a.ltw))) < a.B;
+                            const bool ok1 = !CK_ || (cur.b0 + ((mrow0 + row1) >> (a.lth + a.ltw))) < a.B;
+                            epi_pair<T, EPI, CK_>(acc[mt][nt][i], acc[mt][nt][i + 1], c0, c1, ok0, ok1, esc[nt], esh[nt], a.oslope, s1[nt], s2[nt]);
+                            acc[mt][nt][i] = ebv[nt]; acc[mt][nt][i + 1] = ebv[nt];
+                        }
                     }
                 }
             };
@@ -351,17 +373,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         // arranged so that a workgroup keeps one N tile).
         __syncthreads();
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             float v1 = s1[nt].x + s1[nt].y, v2 = s2[nt].x + s2[nt].y;
             if constexpr (EPI == EPI_BWD) v2 = eis[nt] * v2 + exm[nt] * v1;   // sum dz*xhat from sum dz*y and sum dz
             v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
-            if (h == 0) { red[((wave * NT + nt) * 32 + r) * 2] = v1; red[((wave * NT + nt) * 32 + r) * 2 + 1] = v2; }
+            if (h == 0) { red[((wave * NTW + nt) * 32 + r) * 2] = v1; red[((wave * NTW + nt) * 32 + r) * 2 + 1] = v2; }
         }
         __syncthreads();
         if (tid < NT * 32) {
             float v1 = 0.f, v2 = 0.f;
+            if constexpr (W22) {   // channel tid lives in the two waves of column wn = tid / (32*NTW)
+                const int cw = tid / (32 * NTW), cl = tid - cw * 32 * NTW;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
+                for (int m = 0; m < 2; ++m) { v1 += red[(((m + 2 * cw) * NTW) * 32 + cl) * 2]; v2 += red[(((m + 2 * cw) * NTW) * 32 + cl) * 2 + 1]; }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
+            }
             const int n0 = (blockIdx.x % ntiles_n) * 32 * NT;
             unsafeAtomicAdd(&a.stat[n0 + tid], (double)v1);
             unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)v2);

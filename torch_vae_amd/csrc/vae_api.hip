@@ -93,7 +93,7 @@ struct vae_ctx {
     // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, use_fused_bn, bwd_dirty;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, use_fused_bn, bwd_dirty;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -158,7 +158,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
@@ -251,6 +251,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_bwd_per_cu")) { c->knob_bwd_per_cu = value; return 0; }
     if (!strcmp(name, "knob_wave_nt_max")) { c->knob_wave_nt_max = value; return 0; }
     if (!strcmp(name, "use_fused_bn")) { c->use_fused_bn = value; return 0; }
+    if (!strcmp(name, "knob_lay22_min_nt")) { c->knob_lay22_min_nt = value; return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
@@ -323,8 +324,10 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     NT = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
     if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
-    // wave-independent tiles (32 pixels per wave, no workgroup barrier in the loop) vs one 128-pixel tile per workgroup
-    const bool wv = sizeof(T) == 2 && NT <= c->knob_wave_nt_max;
+    // tile organisation: 2x2 wave grid over a 128-pixel workgroup tile (wide down tiles: halves the weight-fragment
+    // traffic), wave-independent 32-pixel tiles (no workgroup barrier in the loop), or one row of waves per workgroup tile
+    const bool lay22 = is_down && NT >= 2 && NT >= c->knob_lay22_min_nt;   // (f32: NT is 2, used by the exact-arithmetic tests)
+    const bool wv = sizeof(T) == 2 && !lay22 && NT <= c->knob_wave_nt_max;
     Tiling t = make_tiling(a.Hs, a.Ws, wv ? 32 : 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
@@ -334,7 +337,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
     const size_t opitch = 32 * NT * sizeof(T) + 16;
-    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (is_down ? 128 : 256) * opitch + 4 * NT * 32 * 2 * 4 +
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (lay22 ? 256 * (16 * NT * sizeof(T) + 16) : (is_down ? 128 : 256) * opitch) + 4 * NT * 32 * 2 * 4 +
                        std::max<size_t>((size_t)TB * PHW * 4, (size_t)(is_down ? 10 : 3) * (wv ? 64 : 256)) * 8;   // + the per-item staging table (padded to MAXI*SSTR)
     if (lds > 160 * 1024) return vae_set_error("conv_pipe", "tile does not fit LDS");
     if (c->knob_ablate_b) a.two_src |= 2;
@@ -351,14 +354,19 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
                  2.0 * 9 * a.Cin * a.Cout * px_lo, st);
     if (((a.two_src & 1) != 0) != (a.epi != EPI_FWD)) return vae_set_error("conv_pipe", "forward launches stage one source, backward launches two");
 #define PIPE_CASE(K, N, E, V) { if (set_lds(K<T, N, E, V>, lds)) return -1; hipLaunchKernelGGL((K<T, N, E, V>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
+#define PIPE_CASE22(N, E) { if (set_lds(down2_kernel<T, N, E, false, 1>, lds)) return -1; hipLaunchKernelGGL((down2_kernel<T, N, E, false, 1>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
 #define PIPE_WV(K, N, E) { if constexpr (sizeof(T) == 2) { if (wv) PIPE_CASE(K, N, E, true) else PIPE_CASE(K, N, E, false) } else PIPE_CASE(K, N, E, false) }
 #define PIPE_EPI(K, N) { if (a.epi == EPI_FWD) PIPE_WV(K, N, EPI_FWD) else if (a.epi == EPI_BWD) PIPE_WV(K, N, EPI_BWD) else PIPE_WV(K, N, EPI_PLAIN) }
-    if (is_down) { if (NT == 1) PIPE_EPI(down2_kernel, 1) else if (NT == 2) PIPE_EPI(down2_kernel, 2) else PIPE_EPI(down2_kernel, 4) }
+#define PIPE_EPI22(N) { if (a.epi == EPI_FWD) PIPE_CASE22(N, EPI_FWD) else if (a.epi == EPI_BWD) PIPE_CASE22(N, EPI_BWD) else PIPE_CASE22(N, EPI_PLAIN) }
+    if (lay22) { if (NT == 2) PIPE_EPI22(2) else { if constexpr (sizeof(T) == 2) PIPE_EPI22(4) } }
+    else if (is_down) { if (NT == 1) PIPE_EPI(down2_kernel, 1) else if (NT == 2) PIPE_EPI(down2_kernel, 2) else PIPE_EPI(down2_kernel, 4) }
     else if (a.epi == EPI_FWD) { if (NT == 1) PIPE_WV(up2_kernel, 1, EPI_FWD) else PIPE_WV(up2_kernel, 2, EPI_FWD) }
     else if (a.epi == EPI_BWD) PIPE_WV(up2_kernel, 1, EPI_BWD)
     else return vae_set_error("conv_pipe", "up kernel has no plain epilogue");
+#undef PIPE_EPI22
 #undef PIPE_EPI
 #undef PIPE_WV
+#undef PIPE_CASE22
 #undef PIPE_CASE
     LAUNCH_CHECK("conv_pipe_kernel");
     return 0;
