@@ -365,7 +365,7 @@ __device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1
 // the matrix pipe (persistent loop over this workgroup's K tiles).  CONVT selects which side carries
 // the two-source gradient operand (ConvTranspose2d: high-res side; Conv2d: low-res side).
 template <typename T, int WA, int WB, bool CONVT, bool PRE>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
+__global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
     // 4 waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
     constexpr int TS = 4 / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);

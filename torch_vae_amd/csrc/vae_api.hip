@@ -93,7 +93,7 @@ struct vae_ctx {
     // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, use_fused_bn, bwd_dirty;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, bwd_dirty;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -158,7 +158,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 512; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
@@ -252,6 +252,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_wave_nt_max")) { c->knob_wave_nt_max = value; return 0; }
     if (!strcmp(name, "use_fused_bn")) { c->use_fused_bn = value; return 0; }
     if (!strcmp(name, "knob_lay22_min_nt")) { c->knob_lay22_min_nt = value; return 0; }
+    if (!strcmp(name, "knob_conv1_grid")) { c->knob_conv1_grid = value; return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
@@ -394,7 +395,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const int WK = 4 / (WA * WB);
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16) +
-                       ((c->use_pipelined && sizeof(T) == 2 && !(WA == 2 && WB == 2)) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)5 * WB * 256) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*256)
+                       ((c->use_pipelined && sizeof(T) == 2) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)5 * WB * 256) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*256)
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
     {
@@ -403,10 +404,10 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
                  2.0 * 9 * a.CA * a.CB * px_s, st);
     // s_two/g_two identify the layer kind: Conv2d (gradient on the low-res side) or ConvTranspose2d
     if (a.s_two == a.g_two) return vae_set_error("wgrad", "exactly one operand must be the gradient");
-    const bool convt = a.g_two != 0, pre = c->use_pipelined && sizeof(T) == 2 && !(WA == 2 && WB == 2);
+    const bool convt = a.g_two != 0, pre = c->use_pipelined && sizeof(T) == 2;
 #define WG_CASE(A_, B_, C_, P_) { if (set_lds(wgrad_kernel<T, A_, B_, C_, P_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_, C_, P_>), grid, dim3(256), lds, st, a); }
 #define WG_KIND(A_, B_, P_) { if (convt) WG_CASE(A_, B_, true, P_) else WG_CASE(A_, B_, false, P_) }
-    if (WA == 2 && WB == 2) WG_KIND(2, 2, false)
+    if (WA == 2 && WB == 2) { if (pre) WG_KIND(2, 2, true) else WG_KIND(2, 2, false) }
     else if (WA == 2 && WB == 1) { if (pre) WG_KIND(2, 1, true) else WG_KIND(2, 1, false) }
     else { if (pre) WG_KIND(1, 1, true) else WG_KIND(1, 1, false) }
 #undef WG_KIND
@@ -660,7 +661,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
     }
     {
         const long P = (long)B * (H / 2) * (H / 2);
-        const int grid = (int)std::min<long>((P + 63) / 64, 512);   // few workgroups: one f64 atomic per channel each
+        const int grid = (int)std::min<long>((P + 63) / 64, c->knob_conv1_grid);   // few workgroups: one f64 atomic per channel each
         ProfScope ps(c, "conv1_fwd", 4.0 * B * H * H + (double)sizeof(T) * 32.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
