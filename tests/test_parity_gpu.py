@@ -477,3 +477,78 @@ def test_execution_options_do_not_change_results(dtype):
         np.testing.assert_allclose(a[0], b[0], rtol=1e-6 if dtype == "f32" else 3e-4)
         assert rel_l2(a[1], b[1]) < (1e-5 if dtype == "f32" else 3e-3)
         assert rel_l2(a[2], b[2]) < (5e-3 if dtype == "f32" else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_properties(dtype):
+    """BASELINE workload size (128x128, latent 16, batch 256 - too large for the numpy oracle in a test): properties
+    that hold at any size, checked with independent torch reductions on the device.
+      * reconstruction term == BCE(xhat, x) from the returned xhat; KL term from the returned mu/log_var;
+      * BatchNorm running statistics of the first and last layer == statistics of the stored activations;
+      * the backward is linear in the upstream gradient: loss*2 gives exactly 2x gradients (powers of two are exact
+        in f32 and bf16), and a second pass over the same batch reproduces the first bit for bit (determinism of the
+        split-K slabs / side streams);
+      * permuting the batch leaves the ELBO and the gradients unchanged up to summation order;
+      * one fused AdamW step == torch.optim.AdamW on the same gradients."""
+    import torch.nn.functional as F
+    from torch_vae_amd import _lib
+    from torch_vae_amd.optim import FusedAdamW
+    H, L, B, gen = 128, 16, 256, True
+    p = perturbed_params(L, H, 5, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 77)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 77, 5).reshape(B, L)).float().cuda()
+    tol = 1e-5 if dtype == "f32" else 2e-4
+    model = make_model(H, L, gen, dtype, p, kld_weight=4.0)
+    out3, xhat = model.fused_forward_backward(x, eps=eps)
+    g1 = model.flat_grads().detach().clone()
+    mu, lv = model._last["mu"], model._last["lv"]
+    assert float(xhat.min()) >= 0.0 and float(xhat.max()) <= 1.0
+    bce = F.binary_cross_entropy(xhat.double(), x.double()).item()
+    kld = (-0.5 * (1 + lv.double() - mu.double() ** 2 - lv.double().exp()).sum(1)).mean().item()
+    np.testing.assert_allclose(out3[1].item(), bce, rtol=tol)
+    np.testing.assert_allclose(-out3[2].item(), kld, rtol=tol)          # the reference's kld_loss carries the flipped sign
+    np.testing.assert_allclose(out3[0].item(), bce + 4.0 * kld, rtol=tol)
+    # BatchNorm statistics of the stored tensors (f64 atomics over 4M / 4M pixels)
+    sd = model.state_dict()
+    for which, key, C, S in ((0, "encoder.0.1", 32, H // 2), (7, "final_layer.1", 32, H)):
+        n = B * C * S * S
+        y = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(model._ctx.handle, which, y.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        y = y.view(B, C, S, S).double()
+        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=True)
+        np.testing.assert_allclose(sd[key + ".running_mean"].cpu().numpy(), (0.1 * mean).cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd[key + ".running_var"].cpu().numpy(), (0.9 + 0.1 * var).cpu().numpy(), rtol=1e-4)
+    # determinism and linearity of the backward
+    out3b, _ = model.fused_forward_backward(x, eps=eps)
+    assert torch.equal(model.flat_grads(), g1) and torch.equal(out3b, out3)
+    m2 = make_model(H, L, gen, dtype, p, kld_weight=4.0)
+    m2.set_next_eps(eps)
+    (2.0 * m2.loss(m2(x))["loss"]).backward()
+    assert torch.equal(m2.flat_grads(), 2.0 * g1)
+    # batch permutation
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    m3 = make_model(H, L, gen, dtype, p, kld_weight=4.0)
+    out3p, _ = m3.fused_forward_backward(x[perm].contiguous(), eps=eps[perm].contiguous())
+    np.testing.assert_allclose(out3p.cpu().numpy(), out3.cpu().numpy(), rtol=1e-5 if dtype == "f32" else 5e-4)
+    gp = m3.flat_grads().double()
+    if dtype == "f32":
+        assert rel_l2(gp.cpu().numpy(), g1.double().cpu().numpy()) < 5e-3
+    else:
+        cos = float((gp * g1.double()).sum() / (gp.norm() * g1.double().norm()))
+        assert cos > 0.97
+    # fused AdamW == torch.optim.AdamW
+    ref_p = model.flat_parameters().detach().clone().requires_grad_(True)
+    ref_p.grad = g1.clone()
+    ref_opt = torch.optim.AdamW([ref_p], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt = FusedAdamW([{"params": list(model.encoder.parameters())}, {"params": list(model.decoder.parameters())}],
+                     lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt._bind()
+    before = model.flat_parameters().detach().clone()
+    opt.step(); ref_opt.step()
+    after = model.flat_parameters().detach()
+    for (o, n) in opt._ranges:
+        np.testing.assert_allclose(after[o:o + n].cpu().numpy(), ref_p.detach()[o:o + n].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    touched = torch.zeros_like(before, dtype=torch.bool)
+    for (o, n) in opt._ranges:
+        touched[o:o + n] = True
+    assert torch.equal(after[~touched], before[~touched])     # fc_mu / fc_var / decoder_input / final_layer are not optimised (train.py:228)
