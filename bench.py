@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# main stream + three side streams + the communication stream: more than HIP's default of 4 hardware queues, and streams
+# that share a queue serialise (measured: +10 % step time once RCCL's streams exist).  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -69,7 +72,7 @@ def main():
     from argparse import Namespace
     from torch_vae_amd import _lib
     from torch_vae_amd.models import VanillaVAE, algorithmic_bytes_per_step, count_flops_per_sample
-    from torch_vae_amd.train import SyntheticPianorollLoader, allreduce_gradients, build_optimizer
+    from torch_vae_amd.train import SyntheticPianorollLoader, build_optimizer, fused_step
 
     H, L, B = args.size, args.latent, args.batch
     gen = H != 32
@@ -88,10 +91,7 @@ def main():
     losses = torch.zeros(3, device=dev)
 
     def step(i):
-        out3, _ = model.fused_forward_backward(batches[i % 4])
-        for w in allreduce_gradients(model, opt):
-            w.wait()
-        opt.step()
+        out3, _ = fused_step(model, opt, batches[i % 4])
         sched.step()
         return out3
 

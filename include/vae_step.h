@@ -101,6 +101,17 @@ int vae_elbo_generic(const float* xhat, const float* target, const float* mu, co
 int vae_backward(vae_ctx* ctx, const float* x, const float* params, float* grads, const float* g_xhat,
                  const float* gscale, const float* g_mu, const float* g_log_var, const float* g_z,
                  const float* g_pre, float kld_weight, int use_std, vae_stream_t stream);
+/* The same backward in two halves, for data-parallel callers that start the all-reduce of the decoder
+ * gradients while the encoder half still runs: part 1 = output conv + decoder stack (on return every decoder
+ * and final_layer gradient is complete in stream order), part 2 = the rest (decoder_input, latent, fc, encoder);
+ * part 0 = both (= vae_backward).  Same arguments in both calls. */
+int vae_backward_part(vae_ctx* ctx, const float* x, const float* params, float* grads, const float* g_xhat,
+                 const float* gscale, const float* g_mu, const float* g_log_var, const float* g_z,
+                 const float* g_pre, float kld_weight, int use_std, int part, vae_stream_t stream);
+/* A non-blocking stream owned by the context, ordered after everything enqueued on `stream` so far.  Data-parallel
+ * callers enqueue the decoder bucket's all-reduce on it right after part 1; it is joined back into the caller's
+ * stream at the end of part 2, so the collective overlaps the encoder half without any host-side handshake. */
+int vae_comm_stream(vae_ctx* ctx, vae_stream_t stream, vae_stream_t* out);
 
 /* torch.optim.AdamW.step (train.py:228,656) on up to two contiguous ranges of the flat
  * buffers (the encoder and decoder groups of train.py:210-225), each with the lr and beta1

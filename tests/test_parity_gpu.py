@@ -552,3 +552,46 @@ def test_full_size_properties(dtype):
     for (o, n) in opt._ranges:
         touched[o:o + n] = True
     assert torch.equal(after[~touched], before[~touched])     # fc_mu / fc_var / decoder_input / final_layer are not optimised (train.py:228)
+
+
+def test_split_backward_and_overlapped_allreduce():
+    """vae_backward_part(1) + (2) == vae_backward (bit for bit), the decoder gradients are final when the hook runs,
+    and train.fused_step under an initialised (single-rank, RCCL) process group takes the same step as without one."""
+    import os as _os
+    import torch.distributed as dist
+    from torch_vae_amd.optim import FusedAdamW
+    from torch_vae_amd.train import fused_step
+    H, L, B, gen = 64, 16, 6, True
+    p = perturbed_params(L, H, 33, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 9)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 9, 5).reshape(B, L)).float().cuda()
+    for dtype in ("f32", "bf16"):
+        m0 = make_model(H, L, gen, dtype, p)
+        m0.fused_forward_backward(x, eps=eps)
+        g0 = m0.flat_grads().detach().clone()
+        m1 = make_model(H, L, gen, dtype, p)
+        seen = {}
+
+        def hook():
+            off, n = m1.group_range("decoder")
+            seen["decoder"] = m1.flat_grads()[off:off + n].detach().clone()
+        m1.fused_forward_backward(x, eps=eps, on_decoder_grads=hook)
+        assert torch.equal(m1.flat_grads(), g0)
+        off, n = m1.group_range("decoder")
+        assert torch.equal(seen["decoder"], g0[off:off + n])
+    # same optimiser step with and without a process group
+    def one_step(use_dist):
+        m = make_model(H, L, gen, "f32", p)
+        opt = FusedAdamW([{"params": list(m.encoder.parameters())}, {"params": list(m.decoder.parameters())}], lr=1e-3)
+        out3, _ = fused_step(m, opt, x, eps=eps)
+        return out3.cpu().numpy(), m.flat_parameters().detach().cpu().numpy().copy()
+    ref = one_step(False)
+    _os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); _os.environ.setdefault("MASTER_PORT", "29571")
+    _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = one_step(True)
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])

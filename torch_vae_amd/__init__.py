@@ -23,7 +23,7 @@ def __getattr__(name):
     if name == "safe_save_model":
         from .utils import safe_save_model
         return safe_save_model
-    if name in ("train_one_epoch", "build_optimizer", "SyntheticPianorollLoader", "allreduce_gradients"):
+    if name in ("train_one_epoch", "build_optimizer", "SyntheticPianorollLoader", "allreduce_gradients", "fused_step"):
         from . import train
         return getattr(train, name)
     raise AttributeError(name)

@@ -93,7 +93,8 @@ struct vae_ctx {
     // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, bwd_dirty;
+    hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, bwd_dirty, bwd_half_done;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -129,7 +130,7 @@ extern "C" void vae_destroy(vae_ctx* c) {
     if (c->n_side_ok) {
         for (int i = 0; i < vae_ctx::NSIDE; ++i) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
         for (int i = 0; i < vae_ctx::NFORK; ++i) (void)hipEventDestroy(c->ev_fork[i]);
-        (void)hipEventDestroy(c->ev_pack);
+        (void)hipEventDestroy(c->ev_pack); (void)hipStreamDestroy(c->comm); (void)hipEventDestroy(c->ev_comm);
     }
     delete c;
 }
@@ -158,9 +159,9 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 512; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 512; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
-    c->packed_for = nullptr; c->bwd_dirty = 1; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
+    c->packed_for = nullptr; c->bwd_dirty = 1; c->bwd_half_done = 0; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
     if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) { vae_set_error("vae_create", "bad dtype"); delete c; return nullptr; }
     if (maxB < 1) { vae_set_error("vae_create", "max_batch < 1"); delete c; return nullptr; }
@@ -226,7 +227,9 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
             for (int i = 0; i < vae_ctx::NSIDE && ok; ++i)
                 ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < vae_ctx::NFORK && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) == hipSuccess;
-            if (ok) ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess;
+            if (ok) ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess &&
+                         hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking) == hipSuccess &&
+                         hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) == hipSuccess;
             c->n_side_ok = ok ? 1 : 0;
         }
     }
@@ -594,6 +597,14 @@ static int join_sides(vae_ctx* c, hipStream_t st) {
     }
     return 0;
 }
+// join the communication stream lent out by vae_comm_stream (work the caller enqueued on it, e.g. an all-reduce)
+static int join_comm(vae_ctx* c, hipStream_t st) {
+    if (!c->comm_busy) return 0;
+    HIP_CHECK_RET(hipEventRecord(c->ev_comm, c->comm));
+    HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_comm, 0));
+    c->comm_busy = 0;
+    return 0;
+}
 template <typename T>
 static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
                        const float* x, float* xhat, hipStream_t st) {
@@ -710,7 +721,7 @@ static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t 
 }
 
 template <typename T>
-static int backward_impl(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+static int backward_first(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
                          const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
                          hipStream_t st) {
     if (!c->B || !c->trained) return vae_set_error("vae_backward", "no train-mode forward to differentiate");
@@ -789,6 +800,16 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
         if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
         if (launch_down<T>(c, a, st)) return -1;
     }
+    return 0;
+}
+
+// second half of the backward: decoder_input / latent / fc / encoder (everything below the decoder stack)
+template <typename T>
+static int backward_second(vae_ctx* c, const float* x, const float* params, float* grads, const float* gscale,
+                           const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                           hipStream_t st) {
+    const int B = c->B, H = c->H, L = c->L;
+    static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // decoder_input backward, reparameterisation + KL backward
     c->tag = "latent";
     {
@@ -888,6 +909,23 @@ static int backward_impl(vae_ctx* c, const float* x, const float* params, float*
     return join_sides(c, st);
 }
 
+// part 0: whole backward; 1: output conv + decoder stack, ending with every decoder gradient complete on `st`
+// (data-parallel callers start that bucket's all-reduce here); 2: the rest.
+template <typename T>
+static int backward_impl(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                         const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                         int part, hipStream_t st) {
+    if (part < 0 || part > 2) return vae_set_error("vae_backward", "part must be 0, 1 or 2");
+    if (part != 2) {
+        if (backward_first<T>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st)) return -1;
+        c->bwd_half_done = 1;
+        if (part == 1) return join_sides(c, st);
+    } else if (!c->bwd_half_done) return vae_set_error("vae_backward", "part 2 before part 1");
+    c->bwd_half_done = 0;
+    if (backward_second<T>(c, x, params, grads, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st)) return -1;
+    return join_comm(c, st);
+}
+
 // ---------------------------------------------------------------------------
 extern "C" int vae_forward(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
                            const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, vae_stream_t stream) {
@@ -937,14 +975,32 @@ extern "C" int vae_elbo_generic(const float* xhat, const float* target, const fl
     return 0;
 }
 
-extern "C" int vae_backward(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
-                            const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
-                            vae_stream_t stream) {
+// A non-blocking stream owned by the context, ordered after everything enqueued on `stream` so far.  Work the caller
+// puts on it (the all-reduce of the decoder gradients after vae_backward_part(..., 1, ...)) is joined back into the
+// caller's stream at the end of vae_backward_part(..., 2, ...).
+extern "C" int vae_comm_stream(vae_ctx* c, vae_stream_t stream, vae_stream_t* out) {
+    if (!c || !out) return vae_set_error("vae_comm_stream", "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev = c->ev_fork[c->fork_rr++ % vae_ctx::NFORK];
+    HIP_CHECK_RET(hipEventRecord(ev, st));
+    HIP_CHECK_RET(hipStreamWaitEvent(c->comm, ev, 0));
+    c->comm_busy = 1;
+    *out = (vae_stream_t)c->comm;
+    return 0;
+}
+extern "C" int vae_backward_part(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                                 const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                                 int part, vae_stream_t stream) {
     if (!c) return vae_set_error("vae_backward", "null ctx");
     if (!x || !params || !grads) return vae_set_error("vae_backward", "null tensor pointer");
     hipStream_t st = (hipStream_t)stream;
-    return c->dtype == VAE_DTYPE_BF16 ? backward_impl<bf16>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st)
-                                      : backward_impl<float>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, st);
+    return c->dtype == VAE_DTYPE_BF16 ? backward_impl<bf16>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, part, st)
+                                      : backward_impl<float>(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, part, st);
+}
+extern "C" int vae_backward(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                            const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                            vae_stream_t stream) {
+    return vae_backward_part(c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, 0, stream);
 }
 
 extern "C" int vae_adamw_step(float* params, const float* grads, float* m, float* v, int ngroups, const int64_t* offsets,

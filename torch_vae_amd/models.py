@@ -271,6 +271,14 @@ class VanillaVAE(nn.Module):
         start = self._offs[idx[0]]
         return start, self._offs[idx[-1]] + self._sizes[idx[-1]] - start
 
+    def comm_stream(self) -> "torch.cuda.Stream":
+        """The context's communication stream, ordered after the work enqueued so far on the current stream; joined
+        back at the end of the backward's second half (include/vae_step.h: vae_comm_stream)."""
+        import ctypes as C
+        out = C.c_void_p()
+        _lib.check(_lib.lib().vae_comm_stream(self._ctx.handle, _stream_ptr(), C.byref(out)), "vae_comm_stream")
+        return torch.cuda.ExternalStream(out.value, device=self._flat.device)
+
     def _require_device(self):
         if self._flat is None:
             raise RuntimeError("VanillaVAE (MI355X) runs only on a HIP device: call model.to('cuda') first; "
@@ -455,9 +463,13 @@ class VanillaVAE(nn.Module):
         return self.forward(x)["output"]
 
     # -- fused step (no autograd): forward, ELBO, backward in one call chain --
-    def fused_forward_backward(self, x: Tensor, eps: Tensor | None = None, use_device_eps: bool = True):
+    def fused_forward_backward(self, x: Tensor, eps: Tensor | None = None, use_device_eps: bool = True,
+                               on_decoder_grads=None):
         """forward -> loss -> backward (train.py:634-650) with gradients written straight into the
-        flat gradient buffer.  Returns a 3-element device tensor {loss, reconstruction, kld_loss}."""
+        flat gradient buffer.  Returns a 3-element device tensor {loss, reconstruction, kld_loss}.
+        ``on_decoder_grads`` (data parallel): called between the two halves of the backward, when every
+        decoder / final_layer gradient is complete in stream order - the caller starts that bucket's
+        all-reduce there so it overlaps the encoder half."""
         self._require_device()
         if eps is None and not use_device_eps:
             eps = torch.randn(x.shape[0], self.latent_dim, device=x.device, dtype=torch.float32)
@@ -466,9 +478,13 @@ class VanillaVAE(nn.Module):
         _lib.check(_lib.lib().vae_loss(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss")
         self._bwd_kld_weight = float(self.kld_weight)
         last = self._last
-        _lib.check(_lib.lib().vae_backward(
-            self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), self._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
-            float(self.kld_weight), 1, _stream_ptr()), "vae_backward")
+        for part in ((0,) if on_decoder_grads is None else (1, 2)):
+            _lib.check(_lib.lib().vae_backward_part(
+                self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), self._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
+                float(self.kld_weight), 1, part, _stream_ptr()), "vae_backward")
+            if part == 1:
+                self.bind_flat_grads()
+                on_decoder_grads()
         self.bind_flat_grads()
         return out3, xhat
 

@@ -11,6 +11,8 @@ still runs through the same kernels via autograd.  With ``torch.distributed`` in
 """
 from __future__ import annotations
 
+import os
+
 import time
 from contextlib import nullcontext
 
@@ -51,20 +53,56 @@ def _dp_world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def allreduce_gradients(model: VanillaVAE, optimizer=None):
-    """Sum the optimised gradient ranges over ranks (RCCL all-reduce over xGMI); the mean is applied
-    inside the AdamW kernel (grad_scale = 1/world).  Returns the async work handles."""
-    world = _dp_world()
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        return []
+def _dist_active() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def _allreduce_range(model: VanillaVAE, prefix: str):
+    """In-line (synchronous-op) all-reduce of one gradient range: torch enqueues the RCCL kernel on the CURRENT stream,
+    so it is ordered by the stream itself.  (Asynchronous ops go through ProcessGroupNCCL's own stream and two
+    event hand-offs, measured at ~0.25 ms per collective on MI355X once the streams sit on different hardware queues.)"""
     g = model.flat_grads()
-    works = []
-    for prefix in ("decoder", "encoder"):  # decoder gradients are produced first by the backward chain
-        off, n = model.group_range(prefix)
-        works.append(dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+    off, n = model.group_range(prefix)
+    dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=False)
+
+
+def allreduce_gradients(model: VanillaVAE, optimizer=None):
+    """Sum the optimised gradient ranges over ranks (RCCL all-reduce over xGMI) on the current stream; the mean is
+    applied inside the AdamW kernel (grad_scale = 1/world).  Returns [] (kept for callers that wait on handles)."""
+    world = _dp_world()
+    if world == 1 and not _dist_active():
+        return []
+    for prefix in ("decoder", "encoder"):  # decoder gradients are produced first
+        _allreduce_range(model, prefix)
     if optimizer is not None and hasattr(optimizer, "grad_scale"):
         optimizer.grad_scale = 1.0 / world
-    return works
+    return []
+
+
+def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool = True, overlap: bool | None = None):
+    """One training step on the fused path (train.py:634-656): forward, ELBO, backward, [gradient all-reduce], AdamW.
+    Data parallel: both gradient buckets are reduced in line on the compute stream after the backward (no stream
+    hand-offs).  ``overlap=True`` (or VAE_DP_OVERLAP=1) instead enqueues the decoder bucket on the context's
+    communication stream between the two halves of the backward so that it overlaps the encoder half; on the single
+    MI355X available during development the hand-off to a second stream cost more than it hid, so it is opt-in."""
+    if overlap is None:
+        overlap = os.environ.get("VAE_DP_OVERLAP", "0") == "1"
+    if not _dist_active():
+        out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
+    else:
+        if overlap:
+            def decoder_bucket():
+                with torch.cuda.stream(model.comm_stream()):
+                    _allreduce_range(model, "decoder")
+            out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps, on_decoder_grads=decoder_bucket)
+        else:
+            out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
+            _allreduce_range(model, "decoder")
+        _allreduce_range(model, "encoder")
+        if hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0 / _dp_world()
+    optimizer.step()
+    return out3, xhat
 
 
 def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, device="cuda", epoch=1, n_epoch=None,
@@ -86,10 +124,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
         y_true = y_true.to(device)
         if fused:
             # train.py:634-656 as one HIP chain: forward, ELBO, backward, [all-reduce], AdamW
-            out3, reconstruction = model.fused_forward_backward(stimuli, use_device_eps=False)
-            for w in allreduce_gradients(model, optimizer):
-                w.wait()
-            optimizer.step()
+            out3, reconstruction = fused_step(model, optimizer, stimuli, use_device_eps=False)
         else:
             with torch.no_grad() if getattr(config, "freeze_encoder", False) else nullcontext():
                 output = model.forward(stimuli)
