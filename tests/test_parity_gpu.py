@@ -74,11 +74,12 @@ def test_f32_step0_matches_reference_fixture(name):
         np.testing.assert_allclose(v[gi], gold["gradsamp/" + n], rtol=1e-2, atol=1e-2 * ref / np.sqrt(v.size) + 1e-9, err_msg=n)  # atol = 1% of the tensor RMS
 
 
-@pytest.mark.parametrize("cfg", [(32, 16, 5, False), (32, 16, 33, False), (64, 32, 3, True), (128, 16, 2, True)])
+@pytest.mark.parametrize("cfg", [(32, 16, 5, False), (32, 16, 33, False), (64, 32, 3, True), (128, 16, 2, True),
+                                 (32, 16, 1, False), (64, 8, 1, True), (32, 128, 7, True), (256, 16, 1, True), (32, 4, 130, False)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_every_tensor_against_oracle(cfg, dtype):
-    """All gradients (full tensors) against the fp64 oracle, with non-trivial BN affine/bias values
-    and ragged batch sizes (not a multiple of any tile)."""
+    """All gradients (full tensors) against the fp64 oracle, with non-trivial BN affine/bias values,
+    ragged batch sizes (not a multiple of any tile), batch 1, the smallest / largest latent sizes and image sizes."""
     H, L, B, gen = cfg
     p = perturbed_params(L, H, 17, gen)
     model = make_model(H, L, gen, dtype, p)
