@@ -265,6 +265,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     while (have) {
         if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A) previous item fully consumed
         STAMP(0)
+        // Weights straight from L1/L2 as the B operand.  vmcnt retires in order, so they are requested FIRST, ahead of
+        // the next item's prefetch burst (issued below): a weight load queued behind the burst could not be consumed
+        // before the whole burst - HBM latency - had returned.  All nine taps when the registers allow it.
+        const int c0 = chunk * CK;
+        constexpr int FRAG_REGS = 16 / 4 * (sizeof(T) == 2 ? 1 : 2);
+        constexpr int DEPTH = NT == 1 ? 4 : ((9 * KS * NTW * FRAG_REGS <= 160) ? ((W22 && EPI != EPI_BWD) ? 6 : 9) : 4);
+        Frag<T> bq[DEPTH][KS][NTW];
+        auto load_b = [&](int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint32_t kg = (uint32_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) bq[slot][ks][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + (wn * NTW + nt) * 32 + r) * (uint32_t)(8 * sizeof(T))));
+            }
+        };
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) load_b(dd, dd);
         if (NCH > 1) load_coefs(chunk * CK);
         write_patch(cur, chunk * CK);
         if (EPI == EPI_BWD && chunk == 0) {
@@ -284,21 +301,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         if (nhave) issue(nxt, nchunk * CK);                // in flight during the MFMAs / epilogue below
 
         STAMP(3)
-        const int c0 = chunk * CK;
         {
-            // weights straight from L1/L2 as the B operand, kept two taps ahead of the matrix pipe
-            constexpr int DEPTH = 4;   // taps of weight fragments in flight (L2 latency ~ 3 tap steps of MFMA work)
-            Frag<T> bq[DEPTH][KS][NTW];
-            auto load_b = [&](int t, int slot) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const uint32_t kg = (uint32_t)t * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bq[slot][ks][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + (wn * NTW + nt) * 32 + r) * (uint32_t)(8 * sizeof(T))));
-                }
-            };
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) load_b(d, d);
             // A fragments one (tap, k-step) ahead of the matrix pipe
             auto load_a = [&](int step, int mt) __attribute__((always_inline)) {
                 const int t = step / KS, ks = step % KS;
