@@ -591,6 +591,19 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     while (have) {
         if (WV) asm volatile("" ::: "memory"); else __syncthreads();   // (A)
         STAMP(0)
+        // weight fragments of the first DEPTH (k-step, tap) steps are requested before the prefetch burst of the next item
+        // (vmcnt retires in order: see down2_kernel); the queue then runs DEPTH steps ahead of the matrix pipe
+        const int c0 = chunk * CK;
+        constexpr int DEPTH = sizeof(T) == 4 ? (NT == 1 ? 4 : 2) : (NT == 1 ? (EPI == EPI_BWD ? 6 : 10) : 4);
+        Frag<T> bq[DEPTH][NT];
+        auto load_b = [&](int st_, int slot) __attribute__((always_inline)) {
+            const int ks = st_ / NTAP, k = st_ % NTAP;
+            const uint32_t kg = (uint32_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[slot][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + nt * 32 + r) * (uint32_t)(8 * sizeof(T))));
+        };
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) if (dd < KS * NTAP) load_b(dd, dd);
         if (NCH > 1) load_coefs(chunk * CK);
         write_patch(cur, chunk * CK);
         STAMP(1)
@@ -604,27 +617,18 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         if (chunk == NCH - 1 && EPI == EPI_BWD) issue_y(cur, 0);   // rows of round 0, hidden behind the MFMAs
         STAMP(3)
 
-        const int c0 = chunk * CK;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             Frag<T> af[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
                 af[o] = load_frag(reinterpret_cast<const T*>(patch + (pbase + (o >> 1) * PW + (o & 1)) * PATCH_PITCH + ks * 32) + h * 8);
-            constexpr int DEPTH = (NT <= 1 ? 4 : 2);
-            Frag<T> bq[DEPTH][NT];
-            auto load_b = [&](int k, int slot) {
-                const uint32_t kg = (uint32_t)tap_t[k] * (Cin >> 3) + ((c0 + ks * 16) >> 3) + h;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[slot][nt] = load_frag(at_bytes(a.wp, (kg * Cout + cur.n0 + nt * 32 + r) * (uint32_t)(8 * sizeof(T))));
-            };
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) load_b(d, d);
 #pragma unroll
             for (int k = 0; k < NTAP; ++k) {
+                const int st_ = ks * NTAP + k;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) mma(acc[tap_cls[k]][nt], af[tap_off[k]], bq[k % DEPTH][nt]);
-                if (k + DEPTH < NTAP) load_b(k + DEPTH, k % DEPTH);
+                for (int nt = 0; nt < NT; ++nt) mma(acc[tap_cls[k]][nt], af[tap_off[k]], bq[st_ % DEPTH][nt]);
+                if (st_ + DEPTH < KS * NTAP) load_b(st_ + DEPTH, st_ % DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
