@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         // weight fragments of the first DEPTH (k-step, tap) steps are requested before the prefetch burst of the next item
         // (vmcnt retires in order: see down2_kernel); the queue then runs DEPTH steps ahead of the matrix pipe
         const int c0 = chunk * CK;
-        constexpr int DEPTH = sizeof(T) == 4 ? (NT == 1 ? 4 : 2) : (NT == 1 ? (EPI == EPI_BWD ? 6 : 10) : 4);
+        constexpr int DEPTH = sizeof(T) == 4 ? (NT == 1 ? 4 : 2) : (NT == 1 ? (EPI == EPI_BWD ? 9 : 10) : 3);
         Frag<T> bq[DEPTH][NT];
         auto load_b = [&](int st_, int slot) __attribute__((always_inline)) {
             const int ks = st_ / NTAP, k = st_ % NTAP;
