@@ -15,7 +15,7 @@
  * vae_forward / vae_backward the context also uses non-blocking side streams of its own
  * (weight packing, weight gradients); they are forked from and joined back into the
  * caller's stream with HIP events before the call returns, so the caller never has to
- * synchronise with them (and the calls can be captured in a hipGraph).  Functions return
+ * synchronise with them.  Functions return
  * 0 on success or a negative code, with the message in vae_last_error().  A context is
  * not re-entrant; use one per process / GPU.
  */
