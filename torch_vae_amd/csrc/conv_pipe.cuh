@@ -10,7 +10,14 @@
 //     written / combined in place (2-byte LDS cells), then streamed out as whole 16-byte chunks,
 //     so every global store (and every y_out load) is a coalesced 16 B per lane;
 //   * BatchNorm statistics stay in registers across all tiles of a workgroup: one f64 atomic per
-//     channel per workgroup at the very end.
+//     channel per workgroup at the very end;
+//   * three tile organisations: four waves in a row over a 128-pixel workgroup tile (two barriers per item),
+//     wave-independent 32-pixel tiles (WV: no barrier in the loop), a 2x2 wave grid over the 128-pixel x 128-channel
+//     tile (LAY = 1: halves the weight-fragment traffic of the deep layers);
+//   * what the ISA and the counters taught: the epilogue kind is a template parameter, staging
+//     coefficients live in registers, validity comes from flag bits of an LDS geometry table, transforms and statistics
+//     use packed f32 math, addresses are 32-bit byte offsets, and weight fragments are requested BEFORE the next
+//     item's prefetch burst because vmcnt retires in order.
 #pragma once
 #include "conv_mfma.cuh"
 #include <type_traits>
