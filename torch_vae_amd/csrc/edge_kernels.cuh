@@ -56,36 +56,37 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(cg * 8 + c) * 9 + t];
     }
-    // UNR pixels per thread per trip: all their input taps are requested before any is used (the loop is latency-bound)
-    constexpr int UNR = 4;
-    for (int p0 = blockIdx.x * 64 + slot; p0 < P; p0 += gridDim.x * 64 * UNR) {
-        float xv[UNR][9];
+    // A thread computes 4 consecutive output pixels of one row (8 channels each): their 3x9 input window is two aligned
+    // float4 loads + one scalar per row instead of 36 scalar loads with bounds checks (W is a multiple of 8, so only
+    // the row above the image and the column left of it can fall outside).
+    const int Wq = Wo >> 2, lq = lw - 2, Q = B * Ho * Wq;
+    for (int q = blockIdx.x * 64 + slot; q < Q; q += gridDim.x * 64) {
+        const int oxq = q & (Wq - 1), oy = (q >> lq) & (Ho - 1), b = q >> (lq + lh);
+        const int ix0 = 8 * oxq;
+        float win[3][9];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int p = p0 + u * gridDim.x * 64, pc = p < P ? p : 0;
-            const int ox = pc & (Wo - 1), oy = (pc >> lw) & (Ho - 1), b = pc >> (lw + lh);
+        for (int rr = 0; rr < 3; ++rr) {
+            const int iy = 2 * oy + rr - 1;
+            const bool rin = iy >= 0;
+            const float* row = x + ((size_t)b * H + (rin ? iy : 0)) * W + ix0;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(row), v1 = *reinterpret_cast<const f32x4*>(row + 4);
+            const float left = (ix0 > 0) ? row[-1] : 0.f;
+            win[rr][0] = rin ? left : 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float v = x[in ? (b * H + iy) * W + ix : 0];
-                xv[u][t] = in ? v : 0.f;
-            }
+            for (int e = 0; e < 4; ++e) { win[rr][1 + e] = rin ? v0[e] : 0.f; win[rr][5 + e] = rin ? v1[e] : 0.f; }
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int p = p0 + u * gridDim.x * 64;
-            if (p < P) {
-                float o[8];
+        for (int u = 0; u < 4; ++u) {
+            float o[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float acc = br[c];
+            for (int c = 0; c < 8; ++c) {
+                float acc = br[c];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) acc += wr[c][t] * xv[u][t];
-                    o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
-                }
-                store8<T>(y + (size_t)p * 32 + cg * 8, o);
+                for (int t = 0; t < 9; ++t) acc += wr[c][t] * win[t / 3][2 * u + t % 3];
+                o[c] = round_as<T>(acc); s1[c] += o[c]; s2[c] += o[c] * o[c];
             }
+            const size_t p = ((size_t)b * Ho + oy) * Wo + 4 * oxq + u;
+            store8<T>(y + p * 32 + cg * 8, o);
         }
     }
 #pragma unroll
