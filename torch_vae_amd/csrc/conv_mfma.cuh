@@ -218,8 +218,9 @@ __global__ __launch_bounds__(256, 2) void down_kernel(ConvArgs<T> a) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s1 += red[((w * NT) * 32 + tid) * 2]; s2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
-            unsafeAtomicAdd(&a.stat[n0 + tid], (double)s1);
-            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)s2);
+            double* st_ = a.stat + stat_rep() * 2 * Cout;
+            unsafeAtomicAdd(&st_[n0 + tid], (double)s1);
+            unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)s2);
         }
     }
 }
@@ -325,8 +326,9 @@ __global__ __launch_bounds__(256, 2) void up_kernel(ConvArgs<T> a) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s1 += red[((w * NT) * 32 + tid) * 2]; s2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
-            unsafeAtomicAdd(&a.stat[n0 + tid], (double)s1);
-            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)s2);
+            double* st_ = a.stat + stat_rep() * 2 * Cout;
+            unsafeAtomicAdd(&st_[n0 + tid], (double)s1);
+            unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)s2);
         }
     }
 }
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
     bsum = wave_sum(bsum);
     if (lane == 0) wred[wave] = bsum;
     __syncthreads();
-    if (tid == 0) unsafeAtomicAdd(&a.accum[0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+    if (tid == 0) unsafeAtomicAdd(&a.accum[stat_rep() * 8 + 0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
 }
 
 // ---------------------------------------------------------------------------
@@ -921,8 +923,8 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
     if (lane == 0) red[wave][352] = sdl;
     __syncthreads();
     for (int j = tid; j < 288; j += 256) a.slab[(size_t)blockIdx.x * 288 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-    if (tid < 64) unsafeAtomicAdd(&a.stat[tid], (double)(red[0][288 + tid] + red[1][288 + tid] + red[2][288 + tid] + red[3][288 + tid]));
-    if (tid == 64) unsafeAtomicAdd(a.dbias, (double)(red[0][352] + red[1][352] + red[2][352] + red[3][352]));
+    if (tid < 64) unsafeAtomicAdd(&a.stat[stat_rep() * 64 + tid], (double)(red[0][288 + tid] + red[1][288 + tid] + red[2][288 + tid] + red[3][288 + tid]));
+    if (tid == 64) unsafeAtomicAdd(a.dbias + stat_rep() * 8, (double)(red[0][352] + red[1][352] + red[2][352] + red[3][352]));
 }
 
 // ---------------------------------------------------------------------------

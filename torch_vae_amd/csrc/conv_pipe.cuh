@@ -401,8 +401,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
                 for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
             }
             const int n0 = (blockIdx.x % ntiles_n) * 32 * NT;
-            unsafeAtomicAdd(&a.stat[n0 + tid], (double)v1);
-            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)v2);
+            double* st_ = a.stat + stat_rep() * 2 * Cout;
+            unsafeAtomicAdd(&st_[n0 + tid], (double)v1);
+            unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)v2);
         }
     }
 }
@@ -707,8 +708,9 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
 #pragma unroll
             for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
             const int n0 = (blockIdx.x % ntiles_n) * 32 * NT;
-            unsafeAtomicAdd(&a.stat[n0 + tid], (double)v1);
-            unsafeAtomicAdd(&a.stat[Cout + n0 + tid], (double)v2);
+            double* st_ = a.stat + stat_rep() * 2 * Cout;
+            unsafeAtomicAdd(&st_[n0 + tid], (double)v1);
+            unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)v2);
         }
     }
 }

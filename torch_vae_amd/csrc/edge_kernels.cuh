@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         float s = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) s += red[wv][ch >> 3][k * 8 + (ch & 7)];
-        unsafeAtomicAdd(&stat[k * 32 + ch], (double)s);
+        unsafeAtomicAdd(&stat[stat_rep() * 64 + k * 32 + ch], (double)s);
     }
 }
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void convout_fwd_kernel(ConvOutArgs a) {
     bsum = wave_sum(bsum);
     if ((tid & 63) == 0) wred[tid >> 6] = bsum;
     __syncthreads();
-    if (tid == 0) unsafeAtomicAdd(&a.accum[0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+    if (tid == 0) unsafeAtomicAdd(&a.accum[stat_rep() * 8 + 0], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
 }
 
 // dlogit = g_xhat * xhat*(1-xhat) [+ gscale * dlogit_std]: caller-supplied dL/dxhat, optionally on top
@@ -340,9 +340,9 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) s += red[wv][ch >> 3][72 + k * 8 + (ch & 7)];
-        unsafeAtomicAdd(&a.stat[k * 32 + ch], (double)s);
+        unsafeAtomicAdd(&a.stat[stat_rep() * 64 + k * 32 + ch], (double)s);
     }
-    if (tid == 64) unsafeAtomicAdd(a.dbias, (double)(red[0][0][88] + red[1][0][88] + red[2][0][88] + red[3][0][88]));
+    if (tid == 64) unsafeAtomicAdd(a.dbias + stat_rep() * 8, (double)(red[0][0][88] + red[1][0][88] + red[2][0][88] + red[3][0][88]));
 }
 
 // ---------------------------------------------------------------------------
@@ -394,9 +394,12 @@ __global__ void latent_fwd_kernel(LatentFwdArgs a) {   // 8 lanes per (b,l): spl
 }
 
 // ELBO scalars (models.py:216-225): loss = bce + kld_weight*kld ; kld_loss reported with flipped sign.
-__global__ void loss_finalize_kernel(const double* accum, float* out3, double inv_n, double inv_b, float kld_weight) {
+// nrep: replicas of the accumulator block (STAT_R for a context's accumulators, 1 for the generic-loss buffer)
+__global__ void loss_finalize_kernel(const double* accum, float* out3, double inv_n, double inv_b, float kld_weight, int nrep) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double bce = accum[0] * inv_n, kld = -0.5 * accum[1] * inv_b;
+        double a0 = 0.0, a1 = 0.0;
+        for (int rep = 0; rep < nrep; ++rep) { a0 += accum[rep * 8 + 0]; a1 += accum[rep * 8 + 1]; }
+        const double bce = a0 * inv_n, kld = -0.5 * a1 * inv_b;
         out3[0] = (float)(bce + (double)kld_weight * kld); out3[1] = (float)bce; out3[2] = (float)(-kld);
     }
 }
@@ -533,8 +536,8 @@ __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
             }
         }
     }
-    unsafeAtomicAdd(&a.stat[c], (double)s1);
-    unsafeAtomicAdd(&a.stat[256 + c], (double)s2);
+    unsafeAtomicAdd(&a.stat[stat_rep() * 512 + c], (double)s1);
+    unsafeAtomicAdd(&a.stat[stat_rep() * 512 + 256 + c], (double)s2);
 }
 
 // dW_mu / dW_var [L][F_ref] = dlat^T @ a4  (K = batch)

@@ -174,21 +174,22 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     const int hs[8] = {H / 2, H / 4, H / 8, H / 16, 2 * c->s, 4 * c->s, 8 * c->s, 16 * c->s};
     size_t nd = 0;
     for (int i = 0; i < 8; ++i) nd += 4 * kBnC[i];
-    c->n_dstats = nd + 8;
+    nd *= STAT_R;                       // replicas (common.cuh: STAT_R)
+    c->n_dstats = nd + 8 * STAT_R;
     c->dstats = dalloc<double>(c, c->n_dstats);
     bool ok = c->dstats != nullptr;
     double* dp = c->dstats;
     for (int i = 0; i < 8 && ok; ++i) {
         BnLayer& l = c->lay[i];
         l.C = kBnC[i]; l.H = hs[i]; l.W = hs[i];
-        l.stat_f = dp; dp += 2 * l.C;
+        l.stat_f = dp; dp += 2 * l.C * STAT_R;
         const size_t n = B * l.H * l.W * l.C;
         l.y = dalloc<char>(c, n * c->esz); l.dz = dalloc<char>(c, n * c->esz); l.block = dalloc<float>(c, LC_ROWS * l.C);
         ok = l.y && l.dz && l.block;
         const int base = i < 4 ? 4 * i : (i < 7 ? 22 + 4 * (i - 4) : 34);
         l.p_convw = base; l.p_convb = base + 1; l.p_gamma = base + 2; l.p_beta = base + 3;
     }
-    for (int i = 0; i < 8; ++i) { c->lay[i].stat_b = dp; dp += 2 * kBnC[i]; }
+    for (int i = 0; i < 8; ++i) { c->lay[i].stat_b = dp; dp += 2 * kBnC[i] * STAT_R; }
     c->accum = dp;
     if (ok) {
         c->d0 = dalloc<char>(c, B * c->F * c->esz); c->dd0 = dalloc<char>(c, B * c->F * c->esz);
@@ -489,6 +490,14 @@ extern "C" int vae_synth_pianoroll(float* x, int B, int H, uint64_t seed, vae_st
     return 0;
 }
 
+// o[0] = sum over the STAT_R replicas of an accumulator slot
+__global__ void accum_to_f32_kernel(const double* slot, float* o) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int rep = 0; rep < STAT_R; ++rep) s += slot[rep * 8];
+        o[0] = (float)s;
+    }
+}
 __global__ void d2f_kernel(const double* s, float* o, int n, float scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = (float)(s[i] * scale);
@@ -727,10 +736,10 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
     if (!c->B || !c->trained) return vae_set_error("vae_backward", "no train-mode forward to differentiate");
     const int B = c->B, H = c->H, L = c->L;
     size_t nfwd = 0;
-    for (int i = 0; i < 8; ++i) nfwd += 2 * kBnC[i];
+    for (int i = 0; i < 8; ++i) nfwd += 2 * kBnC[i] * STAT_R;
     if (c->bwd_dirty) {   // (the forward zeroed every accumulator; only a repeated backward has to clear its own)
         HIP_CHECK_RET(hipMemsetAsync(c->dstats + nfwd, 0, nfwd * sizeof(double), st));   // stat_b
-        HIP_CHECK_RET(hipMemsetAsync(c->accum + 2, 0, sizeof(double), st));
+        for (int rep = 0; rep < STAT_R; ++rep) HIP_CHECK_RET(hipMemsetAsync(c->accum + rep * 8 + 2, 0, sizeof(double), st));
     }
     c->bwd_dirty = 1;
     const float* dl_src = c->dlogit; const float* dl_scale = gscale;
@@ -770,8 +779,8 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         SideFork f = fork_side(c, st, 0);   // the kernel above wrote its partial sums into side stream 0's slab
         if (f.rc) return f.rc;
         if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st, c)) return -1;
-        hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39], 1, 1.f);
-        LAUNCH_CHECK("d2f_kernel");
+        hipLaunchKernelGGL(accum_to_f32_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39]);
+        LAUNCH_CHECK("accum_to_f32_kernel");
     }
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
     for (int i = 7; i >= 4; --i) {
@@ -955,7 +964,7 @@ extern "C" int vae_decode(vae_ctx* c, const float* z, int B, const float* params
 extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
     if (!c || !c->B) return vae_set_error("vae_loss", "no forward");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->accum, out3,
-                       1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight);
+                       1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight, STAT_R);
     LAUNCH_CHECK("loss_finalize_kernel");
     return 0;
 }
@@ -970,7 +979,7 @@ extern "C" int vae_elbo_generic(const float* xhat, const float* target, const fl
     LAUNCH_CHECK("bce_kernel");
     hipLaunchKernelGGL(kld_only_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, mu, lv, g_generic_accum, B * L, kld_weight / (float)B, g_mu, g_lv);
     LAUNCH_CHECK("kld_only_kernel");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, g_generic_accum, out3, 1.0 / (double)n, 1.0 / (double)B, kld_weight);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, g_generic_accum, out3, 1.0 / (double)n, 1.0 / (double)B, kld_weight, 1);
     LAUNCH_CHECK("loss_finalize_kernel");
     return 0;
 }
