@@ -676,13 +676,25 @@ __global__ void pack_kernel(const PackDesc* __restrict__ descs) {
     T* dst = reinterpret_cast<T*>(d.dst);
     // 32-bit index arithmetic (every image is far below 2^31 elements): the 64-bit divisions dominated this kernel
     const int total = (int)d.n;
+    if (d.kind == 0) {
+        // conv weights [A][Bc][9] -> [tap][K/8][N][8]: a thread reads the 9 contiguous taps of one (a, b) pair (coalesced
+        // 36-byte reads) and scatters them to the 9 tap planes
+        const int K = d.k_is_first ? d.A : d.Bc, N = d.k_is_first ? d.Bc : d.A, pairs = d.A * d.Bc;
+        for (int pr = blockIdx.x * blockDim.x + threadIdx.x; pr < pairs; pr += gridDim.x * blockDim.x) {
+            const int ai = pr / d.Bc, bi = pr - ai * d.Bc;
+            const int k = d.k_is_first ? ai : bi, n = d.k_is_first ? bi : ai;
+            const float* sp = d.src + (size_t)pr * 9;
+            float w[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[t] = sp[t];
+            const int o = ((k >> 3) * N + n) * 8 + (k & 7), plane = (K >> 3) * N * 8;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dst[t * plane + o] = fromfloat<T>(w[t]);
+        }
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (d.kind == 0) {
-            const int K = d.k_is_first ? d.A : d.Bc, N = d.k_is_first ? d.Bc : d.A;
-            const int e = i & 7; int r = i >> 3; const int n = r % N; r /= N; const int kg = r % (K >> 3); const int t = r / (K >> 3);
-            const int k = kg * 8 + e;
-            const int ai = d.k_is_first ? k : n, bi = d.k_is_first ? n : k;
-            dst[i] = fromfloat<T>(d.src[(ai * d.Bc + bi) * 9 + t]);
         } else if (d.kind == 1) {
             const int e = i & 7; const int r = i >> 3; const int n = r % d.npad; const int fp = (r / d.npad) * 8 + e;
             const int F = 256 * d.s2; const int fr = (fp & 255) * d.s2 + (fp >> 8);
