@@ -209,16 +209,23 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
     };
-    auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
-        int ey[MAXI];
+    // Transform + store the staged chunks of item g and, chunk by chunk as its registers become free, request the same
+    // chunk of the NEXT item gn (one table entry serves both: the table is tile-independent).  Starting the next burst
+    // here instead of after the barrier lengthens its flight time by the whole transform phase.
+    auto write_patch = [&](const TileGeo& g, int c0, const TileGeo& gn, int cn0, bool nhave_) __attribute__((always_inline)) {
+        int2 e[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it].y; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it]; }
+        const int nbase = tile_base(gn, cn0);
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
             Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
-            if (!item_ok(g, it, ey[u])) o = zero_vec16<T>();
-            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((ey[u] & 0x1fff) << 4)) = o;
+            if (!item_ok(g, it, e[u].y)) o = zero_vec16<T>();
+            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((e[u].y & 0x1fff) << 4)) = o;
+            const uint32_t gi = (nhave_ & item_ok(gn, it, e[u].y)) ? (uint32_t)(nbase + e[u].x) : 0u;
+            pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
+            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
         // patches larger than MAXI*SSTR chunks (tiny spatial sizes, many images per tile): synchronous tail
         for (int it = stid + MAXI * SSTR; it < nitems; it += SSTR) {
@@ -290,7 +297,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) load_b(dd, dd);
         if (NCH > 1) load_coefs(chunk * CK);
-        write_patch(cur, chunk * CK);
+        int npi = pi, nchunk = chunk + 1;
+        TileGeo nxt = cur;
+        if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
+        const bool nhave = npi < n_pairs;
+        write_patch(cur, chunk * CK, nxt, nchunk * CK, nhave);   // ... and the next item's loads, in flight from here on
         if (EPI == EPI_BWD && chunk == 0) {
 #pragma unroll
             for (int u = 0; u < OPL; ++u) {
@@ -301,11 +312,6 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         STAMP(1)
         if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B) patch published
         STAMP(2)
-        int npi = pi, nchunk = chunk + 1;
-        TileGeo nxt = cur;
-        if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
-        const bool nhave = npi < n_pairs;
-        if (nhave) issue(nxt, nchunk * CK);                // in flight during the MFMAs / epilogue below
 
         STAMP(3)
         {
@@ -519,16 +525,23 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
     };
-    auto write_patch = [&](const TileGeo& g, int c0) __attribute__((always_inline)) {
-        int ey[MAXI];
+    // Transform + store the staged chunks of item g and, chunk by chunk as its registers become free, request the same
+    // chunk of the NEXT item gn (one table entry serves both: the table is tile-independent).  Starting the next burst
+    // here instead of after the barrier lengthens its flight time by the whole transform phase.
+    auto write_patch = [&](const TileGeo& g, int c0, const TileGeo& gn, int cn0, bool nhave_) __attribute__((always_inline)) {
+        int2 e[MAXI];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; ey[u] = itab[it].y; }
+        for (int u = 0; u < MAXI; ++u) { const int it = stid + u * SSTR; e[u] = itab[it]; }
+        const int nbase = tile_base(gn, cn0);
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
             Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
-            if (!item_ok(g, it, ey[u])) o = zero_vec16<T>();
-            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((ey[u] & 0x1fff) << 4)) = o;
+            if (!item_ok(g, it, e[u].y)) o = zero_vec16<T>();
+            if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((e[u].y & 0x1fff) << 4)) = o;
+            const uint32_t gi = (nhave_ & item_ok(gn, it, e[u].y)) ? (uint32_t)(nbase + e[u].x) : 0u;
+            pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
+            if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
         }
         for (int it = stid + MAXI * SSTR; it < nitems; it += SSTR) {
             const int2 e = itab[it];
@@ -613,15 +626,14 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) if (dd < KS * NTAP) load_b(dd, dd);
         if (NCH > 1) load_coefs(chunk * CK);
-        write_patch(cur, chunk * CK);
-        STAMP(1)
-        if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B)
-        STAMP(2)
         int npi = pi, nchunk = chunk + 1;
         TileGeo nxt = cur;
         if (nchunk == NCH) { nchunk = 0; npi += pstride; if (npi < n_pairs) nxt = decode_pair(a, npi, ntiles_n, 32 * NT); }
         const bool nhave = npi < n_pairs;
-        if (nhave) issue(nxt, nchunk * CK);
+        write_patch(cur, chunk * CK, nxt, nchunk * CK, nhave);
+        STAMP(1)
+        if (WV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();   // (B)
+        STAMP(2)
         if (chunk == NCH - 1 && EPI == EPI_BWD) issue_y(cur, 0);   // rows of round 0, hidden behind the MFMAs
         STAMP(3)
 
