@@ -524,17 +524,36 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
             __syncthreads();
         } else {
             __syncthreads();                       // previous tile consumed
+            // transform + store this tile's chunks and, as each register pair becomes free, request the same chunk of the
+            // next tile (the loads then fly during the rest of the staging phase as well as the MFMA phase)
+            const bool nh = tile + 1 < t_end;
+            int nb0 = b0, ny0 = y0, nx0 = x0;
+            if (nh) tile_origin(tile + 1, nb0, ny0, nx0);
+            const int nsbase = ((nb0 * Hs + ny0) * Ws + nx0) * CA;
+            const int ngbase = ((nb0 * Hg + 2 * ny0 - 1) * Wg + 2 * nx0 - 1) * CB + bc0;
+            const int ntmask = (ny0 == 0 ? 1 << 13 : 0) | (nx0 == 0 ? 1 << 14 : 0), nnb = a.B - nb0;
 #pragma unroll
             for (int u = 0; u < WA; ++u) {
                 Vec16<T> o = xform2(ps0[u], ps1[S_TWO ? u : 0], ks0, ks1, ks2, S_TWO, a.sslope);
                 if ((b0 + (sloff[u] >> 20)) >= a.B) o = zero_vec16<T>();
                 *reinterpret_cast<Vec16<T>*>(stile + (sloff[u] & 0xfffff)) = o;
+                const uint32_t g = (nh & ((nb0 + (sloff[u] >> 20)) < a.B)) ? (uint32_t)(nsbase + srel[u]) * (uint32_t)sizeof(T) : 0u;
+                ps0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s0) + g);
+                if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s1) + g);
             }
+            int2 e[MAXG];
+#pragma unroll
+            for (int u = 0; u < MAXG; ++u) e[u] = gtab[tid + u * 256];
 #pragma unroll
             for (int u = 0; u < MAXG; ++u) {
                 Vec16<T> o = xform2(pg0[u], pg1[G_TWO ? u : 0], kg0, kg1, kg2, G_TWO, a.gslope);
                 if (gmeta[u] < 0) o = zero_vec16<T>();
                 if (tid + u * 256 < npix * GCH) *reinterpret_cast<Vec16<T>*>(gtile + ((gmeta[u] & 0x1fff) << 4)) = o;
+                const bool ok = nh & ((e[u].y & ntmask) == 0) & ((e[u].y >> 15) < nnb);
+                gmeta[u] = ok ? e[u].y : (e[u].y | (1 << 31));
+                const uint32_t g = ok ? (uint32_t)(ngbase + e[u].x) * (uint32_t)sizeof(T) : 0u;
+                pg0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g0) + g);
+                if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g1) + g);
             }
             // patches with more than MAXG*256 chunks (many small images per tile): synchronous remainder
             for (int it = tid + MAXG * 256; it < npix * GCH; it += 256) {
@@ -545,7 +564,6 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
                 *reinterpret_cast<Vec16<T>*>(gtile + loff) = v;
             }
             __syncthreads();                       // tile published
-            if (tile + 1 < t_end) issue_tile(tile + 1);
         }
 
 #pragma unroll 1
