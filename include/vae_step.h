@@ -159,6 +159,9 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
  *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
  *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
+ *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
+ *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
+ *                           what its producer wrote last finds it in L2 / the memory-side cache
  *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks
  *   knob_nt_max [4], knob_up_per_cu [4], knob_convout_grid [2048], knob_pipe_max_cout [256], knob_bwd_per_cu [0],
  *   knob_wgrad_tile [1], knob_wgrad_wgs [1024], knob_wgrad_cap_mb [48], knob_ablate_b [0]   grid / tile sizing */

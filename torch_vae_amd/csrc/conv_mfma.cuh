@@ -36,6 +36,7 @@ template <typename T> struct ConvArgs {
     unsigned m_pp, m_pw, m_tx, m_txy;                              // fastdiv magics: PP, PW, tiles_x, tiles_x*tiles_y
     long long* dbg;                                                // diagnostic builds only: per-wave phase cycle counters
     BnFuse fuse;                                                   // mode != 0: derive the staging coefficients from batch statistics (pipelined kernels)
+    int rev, n_mt;                                                 // walk the M tiles in reverse order (n_mt of them)
 };
 
 // x / d for small x via one mul_hi: m = ceil(2^32 / d), exact for x, d < 2^16
@@ -345,7 +346,7 @@ template <typename T> struct WgradArgs {
     int s_two, g_two;
     int B, Hs, Ws, CA, CB;
     int lth, ltw, lTB, tiles_x, tiles_y, n_tiles, tiles_per_split;
-    int use_tr16;
+    int use_tr16, rev;
     unsigned m_pp, m_pw, m_tx, m_txy;
     BnFuse fuse;                                                 // mode == BNF_BWD: the gradient operand's coefficients come from batch statistics
 };
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
         ok = b < a.B && iy >= 0 && iy < Hg && ix >= 0 && ix < Wg;
         g = (((size_t)b * Hg + iy) * Wg + ix) * CB + bc0 + qq * E16;
     };
-    auto tile_origin = [&](int tile, int& b0, int& y0, int& x0) {
+    auto tile_origin = [&](int tile_, int& b0, int& y0, int& x0) {
+        const int tile = a.rev ? a.n_tiles - 1 - tile_ : tile_;   // reversed walk (see ConvArgs::rev)
         const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         b0 = bt << a.lTB; y0 = ty << a.lth; x0 = tx << a.ltw;
     };
@@ -512,8 +514,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
     };
     if constexpr (PRE) { if (t_begin < t_end) issue_tile(t_begin); }
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
-        const int b0 = bt << a.lTB, y0 = ty << a.lth, x0 = tx << a.ltw;
+        int b0, y0, x0; tile_origin(tile, b0, y0, x0);
         if constexpr (!PRE) {
             __syncthreads();
             // coefficient rows are stored tile-local (stride 32*WA / 32*WB), channel index = chunk*E16
@@ -678,6 +679,7 @@ struct ConvOutFwdMfmaArgs {
     float* xhat; float* dlogit; double* accum;
     int B, H, W, n_tiles; float inv_n, slope;
     BnFuse fuse;
+    int rev;
 };
 
 __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfmaArgs a) {
@@ -703,7 +705,8 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
     const float bo = a.bias[0];
     float bsum = 0.f;
 
-    auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    auto tile_origin = [&](int tile_, int& b, int& y0, int& x0) {
+        const int tile = a.rev ? a.n_tiles - 1 - tile_ : tile_;   // reversed walk: start with what the producer wrote last
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
         b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
     };
@@ -802,6 +805,7 @@ struct ConvOutBwdMfmaArgs {
     const bf16* yf; const float* ocoef; const float* wt; const float* dlogit; const float* gscale;
     bf16* dz; float* slab; double* stat; double* dbias;
     int B, H, W, n_tiles; float slope;
+    int rev;
 };
 
 __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfmaArgs a) {
@@ -826,7 +830,8 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
     for (int i = 0; i < 16; ++i) accw[i] = 0.f;
     float s1 = 0.f, s2 = 0.f, sdl = 0.f;
 
-    auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    auto tile_origin = [&](int tile_, int& b, int& y0, int& x0) {
+        const int tile = a.rev ? a.n_tiles - 1 - tile_ : tile_;   // reversed walk: start with what the producer wrote last
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
         b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
     };

@@ -63,7 +63,8 @@ __device__ __forceinline__ void epi_pair(float a0, float a1, T* c0, T* c1, bool 
 
 template <typename T>
 __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int ntiles_n, int nch_out) {
-    const int mt = pi / ntiles_n, nt = pi - mt * ntiles_n;
+    int mt = pi / ntiles_n; const int nt = pi - mt * ntiles_n;
+    if (a.rev) mt = a.n_mt - 1 - mt;   // reversed walk over the M tiles (the N tile of a workgroup stays)
     const int bt = fastdiv(mt, a.m_txy), trem = mt - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
     TileGeo g; g.b0 = bt << a.lTB; g.y0 = ty << a.lth; g.x0 = tx << a.ltw; g.n0 = nt * nch_out;
     return g;

@@ -94,7 +94,7 @@ struct vae_ctx {
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
     hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, bwd_dirty, bwd_half_done;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, knob_rev, walk_dir, bwd_dirty, bwd_half_done;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -159,7 +159,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->bwd_half_done = 0; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
@@ -257,6 +257,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_fused_bn")) { c->use_fused_bn = value; return 0; }
     if (!strcmp(name, "knob_lay22_min_nt")) { c->knob_lay22_min_nt = value; return 0; }
     if (!strcmp(name, "knob_conv1_grid")) { c->knob_conv1_grid = value; return 0; }
+    if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
@@ -341,6 +342,8 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     a.m_pp = fastdiv_magic(PHW); a.m_pw = fastdiv_magic(is_down ? 2 * tw + 1 : tw + 1);
     a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int ntn = a.Cout / (32 * NT), n_pairs = n_mt * ntn;
+    a.n_mt = n_mt; a.rev = ((c->knob_rev >> 2) & 1) ? ((a.epi == EPI_FWD) ? ((c->knob_rev >> 4) & 1) : 1) : 0;   // bit 2: backward launches, bit 4: forward too
+    if (c->knob_rev & 32) { a.rev = c->walk_dir; c->walk_dir ^= 1; }   // bit 5: alternate the direction launch by launch
     const size_t opitch = 32 * NT * sizeof(T) + 16;
     const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (lay22 ? 256 * (16 * NT * sizeof(T) + 16) : (is_down ? 128 : 256) * opitch) + 4 * NT * 32 * 2 * 4 +
                        std::max<size_t>((size_t)TB * PHW * 4, (size_t)(is_down ? 10 : 3) * (wv ? 64 : 256)) * 8;   // + the per-item staging table (padded to MAXI*SSTR)
@@ -394,7 +397,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
     a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
-    a.slab = slab_buf; a.use_tr16 = c->use_tr16;
+    a.slab = slab_buf; a.use_tr16 = c->use_tr16; a.rev = (c->knob_rev >> 3) & 1;
     a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const int WK = 4 / (WA * WB);
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
@@ -651,7 +654,7 @@ static int decode_impl(vae_ctx* c, const float* z, int B, const float* params, f
         if (input_bn_fwd(c, 7, params, bn_running, nbt, train, mfma_out, &f7, st)) return -1;
         ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
         if (mfma_out) {
-            ConvOutFwdMfmaArgs m; m.fuse = f7;
+            ConvOutFwdMfmaArgs m; m.fuse = f7; m.rev = c->knob_rev & 1;
             m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.coef = a.coef; m.wt = a.wt; m.bias = a.bias; m.target = x;
             m.xhat = xhat; m.dlogit = c->dlogit; m.accum = c->accum; m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
             m.inv_n = a.inv_n; m.slope = kSlope;
@@ -669,7 +672,7 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
                         const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, hipStream_t st) {
     const int H = c->H, L = c->L;
     c->B = B; c->trained = train; c->x = x; c->xhat = xhat; c->mu = mu; c->lv = lv; c->z = z;
-    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st)); c->bwd_dirty = 0;
+    HIP_CHECK_RET(hipMemsetAsync(c->dstats, 0, c->n_dstats * sizeof(double), st)); c->bwd_dirty = 0; c->walk_dir = 1;
     static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     // encoder block 0 (reads the raw f32 weights); the MFMA layers' packed weight images are built meanwhile
     c->tag = kLayerTag[0];
@@ -763,7 +766,7 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         int grid = (int)std::min<long>((P + 63) / 64, 1024);
         ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
         if (sizeof(T) == 2 && c->use_mfma_convout) {
-            ConvOutBwdMfmaArgs m;
+            ConvOutBwdMfmaArgs m; m.rev = (c->knob_rev >> 1) & 1;
             m.yf = reinterpret_cast<const bf16*>(c->lay[7].y); m.ocoef = a.ocoef; m.wt = a.wt; m.dlogit = a.dlogit; m.gscale = a.gscale;
             m.dz = reinterpret_cast<bf16*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat; m.dbias = a.dbias;
             m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32); m.slope = kSlope;
