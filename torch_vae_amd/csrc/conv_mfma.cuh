@@ -367,15 +367,18 @@ __device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1
 // PRE = true: the next K tile's operand chunks are loaded into registers while the current tile is in
 // the matrix pipe (persistent loop over this workgroup's K tiles).  CONVT selects which side carries
 // the two-source gradient operand (ConvTranspose2d: high-res side; Conv2d: low-res side).
-template <typename T, int WA, int WB, bool CONVT, bool PRE>
-__global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
-    // 4 waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
-    constexpr int TS = 4 / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
+// NW = waves per workgroup (4, or 8 for the 128x32-channel tile of the wide layers: twice the channels per staged byte).
+template <typename T, int WA, int WB, bool CONVT, bool PRE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4) ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
+    // NW waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
+    static_assert(NW == 4 || PRE, "the 8-wave layout exists for the prefetching variant only");
+    constexpr int NTHR = 64 * NW, SIT = WG_KP * 4 * WA / NTHR;   // threads; low-res chunks per thread
+    constexpr int TS = NW / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
     constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
     constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
     constexpr bool S_TWO = !CONVT, G_TWO = CONVT;
-    constexpr int MAXG = 5 * WB;
+    constexpr int MAXG = (5 * WB * 256 + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
     // tile-independent staging table of the high-res patch: {relative element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
     int2* gtab = reinterpret_cast<int2*>(gtile + npix * GPITCH);
     if constexpr (PRE) {   // (padded to MAXG*256 entries; padding entries carry image 0xffff, which never passes the batch test)
-        for (int it = tid; it < max(npix * GCH, MAXG * 256); it += 256) {
+        for (int it = tid; it < max(npix * GCH, MAXG * NTHR); it += NTHR) {
             const int pix = it / GCH, qq = it - pix * GCH;
             const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
             gtab[it] = it < npix * GCH ? make_int2(((img * Hg + py) * Wg + px) * CB + qq * E16,
@@ -402,14 +405,14 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
 
     // staging coefficients (tile-local rows); the gradient operand's may be derived here from the batch statistics
     if (a.fuse.mode == BNF_BWD && a.s_two) {
-        for (int i = tid; i < 32 * WA; i += 256) bn_fused_channel(a.fuse, a0 + i, false, cfs[i], cfs[32 * WA + i], cfs[2 * 32 * WA + i]);
+        for (int i = tid; i < 32 * WA; i += NTHR) bn_fused_channel(a.fuse, a0 + i, false, cfs[i], cfs[32 * WA + i], cfs[2 * 32 * WA + i]);
     } else {
-        for (int i = tid; i < 3 * 32 * WA; i += 256) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
+        for (int i = tid; i < 3 * 32 * WA; i += NTHR) cfs[i] = a.scoef[(i / (32 * WA)) * CA + a0 + (i % (32 * WA))];
     }
     if (a.fuse.mode == BNF_BWD && a.g_two) {
-        for (int i = tid; i < 32 * WB; i += 256) bn_fused_channel(a.fuse, bc0 + i, false, cfg[i], cfg[32 * WB + i], cfg[2 * 32 * WB + i]);
+        for (int i = tid; i < 32 * WB; i += NTHR) bn_fused_channel(a.fuse, bc0 + i, false, cfg[i], cfg[32 * WB + i], cfg[2 * 32 * WB + i]);
     } else {
-        for (int i = tid; i < 3 * 32 * WB; i += 256) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
+        for (int i = tid; i < 3 * 32 * WB; i += NTHR) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
     }
 
     f32x16 acc[NTW];
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
     };
     // prefetch registers.  A thread always stages the same 16-byte channel quarter of both operands (256 is a
     // multiple of the chunks per pixel), so its coefficients live in registers; offsets are 32-bit bytes.
-    Vec16<T> ps0[PRE ? WA : 1], ps1[(PRE && S_TWO) ? WA : 1], pg0[PRE ? MAXG : 1], pg1[(PRE && G_TWO) ? MAXG : 1];
-    int srel[PRE ? WA : 1], sloff[PRE ? WA : 1];     // low-res operand: tile-independent element offset / LDS offset | image << 20
+    Vec16<T> ps0[PRE ? SIT : 1], ps1[(PRE && S_TWO) ? SIT : 1], pg0[PRE ? MAXG : 1], pg1[(PRE && G_TWO) ? MAXG : 1];
+    int srel[PRE ? SIT : 1], sloff[PRE ? SIT : 1];     // low-res operand: tile-independent element offset / LDS offset | image << 20
     int gmeta[PRE ? MAXG : 1];                        // high-res operand: table word of the chunk (LDS offset, halo flags, image)
     constexpr int NE = Vec16<T>::N;
     f32x2 ks0[PRE ? NE / 2 : 1], ks1[(PRE && S_TWO) ? NE / 2 : 1], ks2[PRE ? NE / 2 : 1];
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
     if constexpr (PRE) {
         __syncthreads();   // coefficient rows / table published
 #pragma unroll
-        for (int u = 0; u < WA; ++u) {
-            const int it = tid + u * 256, k = it / SCH, qq = it - k * SCH;
+        for (int u = 0; u < SIT; ++u) {
+            const int it = tid + u * NTHR, k = it / SCH, qq = it - k * SCH;
             const int img = k >> (a.lth + a.ltw), y = (k >> a.ltw) & (th - 1), x = k & (tw - 1);
             srel[u] = ((img * Hs + y) * Ws + x) * CA + a0 + qq * E16;
             sloff[u] = (k * SPITCH + qq * 16) | (img << 20);
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
         int b0, y0, x0; tile_origin(tile, b0, y0, x0);
         const int sbase = ((b0 * Hs + y0) * Ws + x0) * CA;
 #pragma unroll
-        for (int u = 0; u < (PRE ? WA : 0); ++u) {
+        for (int u = 0; u < (PRE ? SIT : 0); ++u) {
             const uint32_t g = (b0 + (sloff[u] >> 20)) < a.B ? (uint32_t)(sbase + srel[u]) * (uint32_t)sizeof(T) : 0u;
             ps0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s0) + g);
             if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s1) + g);
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
         const int tmask = (y0 == 0 ? 1 << 13 : 0) | (x0 == 0 ? 1 << 14 : 0), nb = a.B - b0;   // uniform per tile
         int2 e[PRE ? MAXG : 1];
 #pragma unroll
-        for (int u = 0; u < (PRE ? MAXG : 0); ++u) e[u] = gtab[tid + u * 256];
+        for (int u = 0; u < (PRE ? MAXG : 0); ++u) e[u] = gtab[tid + u * NTHR];
 #pragma unroll
         for (int u = 0; u < (PRE ? MAXG : 0); ++u) {
             const bool ok = ((e[u].y & tmask) == 0) & ((e[u].y >> 15) < nb);
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
             const int ngbase = ((nb0 * Hg + 2 * ny0 - 1) * Wg + 2 * nx0 - 1) * CB + bc0;
             const int ntmask = (ny0 == 0 ? 1 << 13 : 0) | (nx0 == 0 ? 1 << 14 : 0), nnb = a.B - nb0;
 #pragma unroll
-            for (int u = 0; u < WA; ++u) {
+            for (int u = 0; u < SIT; ++u) {
                 Vec16<T> o = xform2(ps0[u], ps1[S_TWO ? u : 0], ks0, ks1, ks2, S_TWO, a.sslope);
                 if ((b0 + (sloff[u] >> 20)) >= a.B) o = zero_vec16<T>();
                 *reinterpret_cast<Vec16<T>*>(stile + (sloff[u] & 0xfffff)) = o;
@@ -544,12 +547,12 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
             }
             int2 e[MAXG];
 #pragma unroll
-            for (int u = 0; u < MAXG; ++u) e[u] = gtab[tid + u * 256];
+            for (int u = 0; u < MAXG; ++u) e[u] = gtab[tid + u * NTHR];
 #pragma unroll
             for (int u = 0; u < MAXG; ++u) {
                 Vec16<T> o = xform2(pg0[u], pg1[G_TWO ? u : 0], kg0, kg1, kg2, G_TWO, a.gslope);
                 if (gmeta[u] < 0) o = zero_vec16<T>();
-                if (tid + u * 256 < npix * GCH) *reinterpret_cast<Vec16<T>*>(gtile + ((gmeta[u] & 0x1fff) << 4)) = o;
+                if (tid + u * NTHR < npix * GCH) *reinterpret_cast<Vec16<T>*>(gtile + ((gmeta[u] & 0x1fff) << 4)) = o;
                 const bool ok = nh & ((e[u].y & ntmask) == 0) & ((e[u].y >> 15) < nnb);
                 gmeta[u] = ok ? e[u].y : (e[u].y | (1 << 31));
                 const uint32_t g = ok ? (uint32_t)(ngbase + e[u].x) * (uint32_t)sizeof(T) : 0u;
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && WA * WB < 4) ? 2 : 1)) voi
                 if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g1) + g);
             }
             // patches with more than MAXG*256 chunks (many small images per tile): synchronous remainder
-            for (int it = tid + MAXG * 256; it < npix * GCH; it += 256) {
+            for (int it = tid + MAXG * NTHR; it < npix * GCH; it += NTHR) {
                 bool ok; size_t g; int loff, cb;
                 g_map(b0, y0, x0, it, ok, g, loff, cb);
                 Vec16<T> v = zero_vec16<T>();

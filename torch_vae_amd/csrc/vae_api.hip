@@ -136,11 +136,12 @@ extern "C" void vae_destroy(vae_ctx* c) {
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
-static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 1;   // tile 1: 64x32 channel tiles (prefetching kernel) also where 64x64 would fit   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
-static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out) {
+static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1;   // wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (bf16 prefetching kernel)
+//   // tile 1: 64x32 channel tiles (prefetching kernel) also where 64x64 would fit   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
+static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out, bool wide_ok = false) {
     int WA, WB;
-    if (CA >= 64 && CB >= 64 && g_wgrad_tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && g_wgrad_tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
-    const int WK = 4 / (WA * WB);
+    if (wide_ok && g_wgrad_wide && CA >= 128 && g_wgrad_tile == 1) { WA = 4; WB = 1; }
+    else if (CA >= 64 && CB >= 64 && g_wgrad_tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && g_wgrad_tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
     Tiling t = make_tiling(Hs, Ws, WG_KP);
     const int TB = 1 << t.lTB;
     const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
@@ -152,7 +153,6 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
     nsplit = std::min(nsplit, n_tiles);
     const int tps = (n_tiles + nsplit - 1) / nsplit;
     nsplit = (n_tiles + tps - 1) / tps;
-    (void)WK;
     *nsplit_out = nsplit; *tps_out = tps; *WA_out = WA; *WB_out = WB;
     return per * nsplit;
 }
@@ -214,8 +214,8 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     size_t slab = 2048 * 288;  // conv1 wgrad / convout bwd: up to 2048 workgroups x 288
     if (ok) {
         int a, b2, wa, wb;
-        for (int i = 1; i < 4; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H, c->lay[i].W, co[i], ci[i], &a, &b2, &wa, &wb));
-        for (int i = 4; i < 8; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H / 2, c->lay[i].W / 2, ci[i], co[i], &a, &b2, &wa, &wb));
+        for (int i = 1; i < 4; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H, c->lay[i].W, co[i], ci[i], &a, &b2, &wa, &wb, dtype == VAE_DTYPE_BF16));
+        for (int i = 4; i < 8; ++i) slab = std::max(slab, wgrad_slab_floats(maxB, c->lay[i].H / 2, c->lay[i].W / 2, ci[i], co[i], &a, &b2, &wa, &wb, dtype == VAE_DTYPE_BF16));
         const size_t ksteps = c->F / 16;
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_fc);
         slab = std::max(slab, (size_t)std::min<size_t>(ksteps, 512) * maxB * c->npad_di);
@@ -259,6 +259,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_conv1_grid")) { c->knob_conv1_grid = value; return 0; }
     if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
+    if (!strcmp(name, "knob_wgrad_wide")) { g_wgrad_wide = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
     return vae_set_error("vae_set_option", "unknown option");
@@ -391,7 +392,7 @@ template <typename T>
 static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st, float* slab_buf = nullptr) {
     if (!slab_buf) slab_buf = c->slab;
     int nsplit, tps, WA, WB;
-    const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB);
+    const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB, c->use_pipelined && sizeof(T) == 2);
     if (need > c->slab_floats) return vae_set_error("wgrad", "slab too small");
     Tiling t = make_tiling(a.Hs, a.Ws, WG_KP);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
@@ -399,10 +400,10 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
     a.slab = slab_buf; a.use_tr16 = c->use_tr16; a.rev = (c->knob_rev >> 3) & 1;
     a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
-    const int WK = 4 / (WA * WB);
+    const int nthr = WA == 4 ? 512 : 256, maxg = (5 * WB * 256 + nthr - 1) / nthr;
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16) +
-                       ((c->use_pipelined && sizeof(T) == 2) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)5 * WB * 256) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*256)
+                       ((c->use_pipelined && sizeof(T) == 2) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)maxg * nthr) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*threads)
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
     {
@@ -414,14 +415,19 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const bool convt = a.g_two != 0, pre = c->use_pipelined && sizeof(T) == 2;
 #define WG_CASE(A_, B_, C_, P_) { if (set_lds(wgrad_kernel<T, A_, B_, C_, P_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_, C_, P_>), grid, dim3(256), lds, st, a); }
 #define WG_KIND(A_, B_, P_) { if (convt) WG_CASE(A_, B_, true, P_) else WG_CASE(A_, B_, false, P_) }
-    if (WA == 2 && WB == 2) { if (pre) WG_KIND(2, 2, true) else WG_KIND(2, 2, false) }
+    if (WA == 4) {
+        if constexpr (sizeof(T) == 2) {
+            if (convt) { if (set_lds(wgrad_kernel<T, 4, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, true, true, 8>), grid, dim3(512), lds, st, a); }
+            else { if (set_lds(wgrad_kernel<T, 4, 1, false, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, false, true, 8>), grid, dim3(512), lds, st, a); }
+        }
+    }
+    else if (WA == 2 && WB == 2) { if (pre) WG_KIND(2, 2, true) else WG_KIND(2, 2, false) }
     else if (WA == 2 && WB == 1) { if (pre) WG_KIND(2, 1, true) else WG_KIND(2, 1, false) }
     else { if (pre) WG_KIND(1, 1, true) else WG_KIND(1, 1, false) }
 #undef WG_KIND
 #undef WG_CASE
     LAUNCH_CHECK("wgrad_kernel");
     }
-    (void)WK;
     return launch_reduce(slab_buf, nsplit, (size_t)9 * a.CA * a.CB, dw_out, a.CA, a.CB, st, c);
 }
 
