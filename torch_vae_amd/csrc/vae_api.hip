@@ -136,9 +136,12 @@ extern "C" void vae_destroy(vae_ctx* c) {
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
-static int g_wgrad_wgs = 1024, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1;   // wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (bf16 prefetching kernel)
+static int g_wgrad_wgs = 256, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1, g_wgrad_wide_wgs = 128, g_wgrad_small_wgs = 1024;
+// workgroup targets: weight gradients run beside the input-gradient chain; on a saturated GPU (large batch x image) few
+// workgroups keep them out of its way (-4 % step time at the bench workload), a small problem wants them everywhere.
+//   // wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (bf16 prefetching kernel)
 //   // tile 1: 64x32 channel tiles (prefetching kernel) also where 64x64 would fit   // split-K sizing (vae_set_option knobs; slabs are sized at vae_create for the defaults)
-static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out, bool wide_ok = false) {
+static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out, bool wide_ok = false, bool big = false) {
     int WA, WB;
     if (wide_ok && g_wgrad_wide && CA >= 128 && g_wgrad_tile == 1) { WA = 4; WB = 1; }
     else if (CA >= 64 && CB >= 64 && g_wgrad_tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && g_wgrad_tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
@@ -147,7 +150,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
     const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
     const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
     const size_t per = (size_t)9 * CA * CB;
-    int nsplit = std::max(1, g_wgrad_wgs / chan_tiles);
+    int nsplit = std::max(1, (!big ? g_wgrad_small_wgs : (WA == 4 ? g_wgrad_wide_wgs : g_wgrad_wgs)) / chan_tiles);
     const size_t cap = ((size_t)g_wgrad_cap_mb << 20) / 4;  // bound slab traffic to 48 MiB per layer
     nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / per));
     nsplit = std::min(nsplit, n_tiles);
@@ -260,6 +263,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { g_wgrad_wide = value; return 0; }
+    if (!strcmp(name, "knob_wgrad_wide_wgs")) { g_wgrad_wide_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
     return vae_set_error("vae_set_option", "unknown option");
@@ -392,7 +396,8 @@ template <typename T>
 static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st, float* slab_buf = nullptr) {
     if (!slab_buf) slab_buf = c->slab;
     int nsplit, tps, WA, WB;
-    const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB, c->use_pipelined && sizeof(T) == 2);
+    const bool big = (double)c->B * c->H * c->H >= (double)(1 << 21);   // e.g. 128x128 at batch >= 128
+    const size_t need = wgrad_slab_floats(a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB, c->use_pipelined && sizeof(T) == 2, big);
     if (need > c->slab_floats) return vae_set_error("wgrad", "slab too small");
     Tiling t = make_tiling(a.Hs, a.Ws, WG_KP);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
