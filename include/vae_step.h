@@ -164,7 +164,8 @@ int vae_selftest_tr16(vae_stream_t stream);
  *                           what its producer wrote last finds it in L2 / the memory-side cache
  *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks
  *   knob_nt_max [4], knob_up_per_cu [4], knob_convout_grid [2048], knob_pipe_max_cout [256], knob_bwd_per_cu [0],
- *   knob_wgrad_tile [1], knob_wgrad_wgs [1024], knob_wgrad_cap_mb [48], knob_ablate_b [0]   grid / tile sizing */
+ *   knob_wgrad_tile [1], knob_wgrad_wide [1], knob_wgrad_wgs [128], knob_wgrad_wide_wgs [128], knob_wgrad_cap_mb [48],
+ *   knob_conv1_grid [1024], knob_ablate_b [0]   grid / tile sizing */
 int vae_set_option(vae_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

@@ -136,7 +136,7 @@ extern "C" void vae_destroy(vae_ctx* c) {
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
-static int g_wgrad_wgs = 256, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1, g_wgrad_wide_wgs = 128, g_wgrad_small_wgs = 1024;
+static int g_wgrad_wgs = 128, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1, g_wgrad_wide_wgs = 128, g_wgrad_small_wgs = 1024;
 // workgroup targets: weight gradients run beside the input-gradient chain; on a saturated GPU (large batch x image) few
 // workgroups keep them out of its way (-4 % step time at the bench workload), a small problem wants them everywhere.
 //   // wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (bf16 prefetching kernel)
