@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (path test)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the product path); gloo only rehearses the multi-rank control flow with ranks sharing one GPU")
     ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE", help="vae_set_option knob (diagnostics)")
     ap.add_argument("--dump-order", default=None, help="write the per-step launch order (label, kernel symbol) as JSON")
     return ap.parse_args()
@@ -63,11 +65,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VAE step has no CPU path")
+    if args.backend == "gloo":   # rehearsal of the N>1 control flow on a one-GPU box: ranks share the card
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from argparse import Namespace
     from torch_vae_amd import _lib
@@ -121,34 +128,48 @@ def main():
     # the throughput of everything running inside the dominant launch's window, and the same launch measured
     # alone (side streams off).
     roofline, kernels = None, []
-    if rank == 0:
-        L_ = _lib.lib()
-        h = model._ctx.handle
-        nprof = 3
+    L_ = _lib.lib()
+    h = model._ctx.handle
+    nprof = 3
 
-        def profile_steps():
+    def profile_steps():
+        # EVERY rank runs these steps (each one contains the gradient all-reduce); only rank 0 records and reads events
+        if rank == 0:
             _lib.check(L_.vae_profile(h, 1), "vae_profile")
-            for i in range(nprof):
-                step(args.warmup + args.steps + i)
-            buf = ctypes.create_string_buffer(1 << 16)
-            _lib.check(L_.vae_profile_report(h, buf, len(buf)), "vae_profile_report")
-            tbuf = ctypes.create_string_buffer(1 << 20)
-            _lib.check(L_.vae_profile_timeline(h, tbuf, len(tbuf)), "vae_profile_timeline")
-            seq = None
-            if args.dump_order:
-                sbuf = ctypes.create_string_buffer(1 << 18)
-                _lib.check(L_.vae_profile_sequence(h, sbuf, len(sbuf)), "vae_profile_sequence")
-                seq = json.loads(sbuf.value.decode())
-            _lib.check(L_.vae_profile(h, 0), "vae_profile")
-            ks = json.loads(buf.value.decode())
-            for k in ks:
-                k["ms_per_call"] = k["ms"] / k["calls"]
-                k["gbs"] = k["bytes"] / k["ms"] / 1e6 if k["ms"] > 0 else 0.0
-                k["tflops"] = k["flops"] / k["ms"] / 1e9 if k["ms"] > 0 else 0.0
-            ks.sort(key=lambda k: -k["ms"])
-            return ks, json.loads(tbuf.value.decode()), seq
+        for i in range(nprof):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        if rank != 0:
+            return None, None, None
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(L_.vae_profile_report(h, buf, len(buf)), "vae_profile_report")
+        tbuf = ctypes.create_string_buffer(1 << 20)
+        _lib.check(L_.vae_profile_timeline(h, tbuf, len(tbuf)), "vae_profile_timeline")
+        seq = None
+        if args.dump_order:
+            sbuf = ctypes.create_string_buffer(1 << 18)
+            _lib.check(L_.vae_profile_sequence(h, sbuf, len(sbuf)), "vae_profile_sequence")
+            seq = json.loads(sbuf.value.decode())
+        _lib.check(L_.vae_profile(h, 0), "vae_profile")
+        ks = json.loads(buf.value.decode())
+        for k in ks:
+            k["ms_per_call"] = k["ms"] / k["calls"]
+            k["gbs"] = k["bytes"] / k["ms"] / 1e6 if k["ms"] > 0 else 0.0
+            k["tflops"] = k["flops"] / k["ms"] / 1e9 if k["ms"] > 0 else 0.0
+        ks.sort(key=lambda k: -k["ms"])
+        return ks, json.loads(tbuf.value.decode()), seq
 
-        kernels, timeline, seq = profile_steps()
+    kernels, timeline, seq = profile_steps()
+    # the same launches alone: side streams off for a few profiled steps (again on every rank)
+    iso = None
+    if not any(kv.startswith("use_side_stream=") for kv in args.set):
+        _lib.check(L_.vae_set_option(h, b"use_side_stream", 0), "vae_set_option")
+        step(0); torch.cuda.synchronize()
+        iso, _, _ = profile_steps()
+        _lib.check(L_.vae_set_option(h, b"use_side_stream", 1), "vae_set_option")
+    if rank != 0:
+        kernels = []
+    else:
         if args.dump_order and seq is not None:
             json.dump(seq[:len(seq) // nprof], open(args.dump_order, "w"))
         dom = kernels[0]
@@ -166,17 +187,11 @@ def main():
                     if n1 != n0 and b1 * ov / (e1 - s1) > 0.02 * dom["bytes"] / dom["calls"]:
                         mates.add(n1)
         window_gbs = wbytes / wtime / 1e6 if wtime > 0 else 0.0
-        # the same launch alone: side streams off for a few profiled steps
         isolated = None
-        if not any(kv.startswith("use_side_stream=") for kv in args.set):
-            _lib.check(L_.vae_set_option(h, b"use_side_stream", 0), "vae_set_option")
-            step(0); torch.cuda.synchronize()
-            iso, _, _ = profile_steps()
-            _lib.check(L_.vae_set_option(h, b"use_side_stream", 1), "vae_set_option")
-            for k in iso:
-                if k["name"] == dom["name"]:
-                    isolated = {"avg_launch_us": round(1e3 * k["ms_per_call"], 2), "achieved": round(k["gbs"], 1),
-                                "frac": round(k["gbs"] / HBM_PEAK_GBS, 4)}
+        for k in iso or []:
+            if k["name"] == dom["name"]:
+                isolated = {"avg_launch_us": round(1e3 * k["ms_per_call"], 2), "achieved": round(k["gbs"], 1),
+                            "frac": round(k["gbs"] / HBM_PEAK_GBS, 4)}
         # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
         # passes; tools/pmc_traffic.py writes profiles/pmc_traffic.json on the GPU box) - null when not collected
         traffic = None

@@ -596,3 +596,22 @@ def test_split_backward_and_overlapped_allreduce():
         dist.destroy_process_group()
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_bench_two_rank_control_flow():
+    """bench.py under torch.distributed.run with two ranks finishes and rank 0 prints ONE JSON line: every rank has to
+    take part in every step that contains the gradient all-reduce, including the profiled steps after the timed
+    region.  Rehearsal only: both ranks share this box's GPU, so the exchange goes through gloo instead of RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29587", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--size", "32", "--batch", "32", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["roofline"]["achieved"] > 0
