@@ -83,6 +83,11 @@ int vae_last_eps(vae_ctx* ctx, float* out, vae_stream_t stream);
 /* VanillaVAE.loss (models.py:190-225) for the last forward: out3 = {loss, reconstruction_loss,
  * kld_loss} with kld_loss sign-flipped as at models.py:224. */
 int vae_loss(vae_ctx* ctx, float kld_weight, float* out3, vae_stream_t stream);
+/* The same scalars computed beside the backward instead of in front of it (one launch less on the critical chain):
+ * enqueued on a context side stream ordered after `stream`; out3 is ordered into the caller's stream by the NEXT
+ * vae_backward / vae_backward_part on this context, which must follow (train-mode forward only).  For callers that read
+ * the ELBO after the step, as train_one_epoch does (train.py:644-674). */
+int vae_loss_deferred(vae_ctx* ctx, float kld_weight, float* out3, vae_stream_t stream);
 
 /* VanillaVAE.loss (models.py:190-225) on arbitrary caller tensors: xhat/target [n], mu/log_var
  * [B,L].  Optional outputs (NULL to skip): unscaled gradients of the loss w.r.t. xhat, mu, log_var
@@ -162,6 +167,9 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
  *                           what its producer wrote last finds it in L2 / the memory-side cache
+ *   knob_lean [7]           launches kept off the critical chain (bit 0 reparameterisation noise drawn beside the first conv,
+ *                           1 BatchNorm backward of encoder block 0 inside its weight-gradient kernel, 2 vae_loss_deferred
+ *                           really on a side stream)
  *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks
  *   knob_nt_max [4], knob_up_per_cu [4], knob_convout_grid [2048], knob_pipe_max_cout [256], knob_bwd_per_cu [0],
  *   knob_wgrad_tile [1], knob_wgrad_wide [1], knob_wgrad_wgs [128], knob_wgrad_wide_wgs [128], knob_wgrad_cap_mb [48],

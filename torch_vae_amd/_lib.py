@@ -61,6 +61,7 @@ def lib():
     _sig(L.vae_pre_latents, i32, [p, p, p])
     _sig(L.vae_last_eps, i32, [p, p, p])
     _sig(L.vae_loss, i32, [p, f32, p, p])
+    _sig(L.vae_loss_deferred, i32, [p, f32, p, p])
     _sig(L.vae_elbo_generic, i32, [p, p, p, p, i64, i32, i32, f32, p, p, p, p, p])
     _sig(L.vae_backward, i32, [p, p, p, p, p, p, p, p, p, p, f32, i32, p])
     _sig(L.vae_backward_part, i32, [p, p, p, p, p, p, p, p, p, p, f32, i32, i32, p])
@@ -83,7 +84,7 @@ def lib():
 
 EXPORTS = [
     "vae_last_error", "vae_abi_version", "vae_param_layout", "vae_bn_layout", "vae_create", "vae_destroy",
-    "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_elbo_generic",
+    "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_loss_deferred", "vae_elbo_generic",
     "vae_backward", "vae_backward_part", "vae_comm_stream", "vae_adamw_step", "vae_train_step", "vae_synth_pianoroll", "vae_profile",
     "vae_profile_report", "vae_profile_sequence", "vae_profile_timeline", "vae_debug_stamps", "vae_debug_tensor",
     "vae_selftest_tr16", "vae_set_option",

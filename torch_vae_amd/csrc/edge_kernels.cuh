@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dz,
                                                           const T* __restrict__ y, const float* __restrict__ gcoef,
-                                                          float* __restrict__ slab, int B, int H, int W) {
+                                                          float* __restrict__ slab, int B, int H, int W, BnFuse fuse) {
     __shared__ float red[4][4][72];
     const int tid = threadIdx.x, cg = tid & 3, slot = tid >> 2, lane = tid & 63, wave = tid >> 6;
     const int Ho = H >> 1, Wo = W >> 1, lw = 31 - __builtin_clz(Wo), lh = 31 - __builtin_clz(Ho);
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     float p0[8], p1[8], p2[8], acc[8][9];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        p0[c] = gcoef[cg * 8 + c]; p1[c] = gcoef[32 + cg * 8 + c]; p2[c] = gcoef[64 + cg * 8 + c];
+        // BatchNorm backward of encoder block 0: derived here from the sums the input-gradient kernel left (no finalise launch)
+        if (fuse.mode == BNF_BWD) bn_fused_channel(fuse, cg * 8 + c, blockIdx.x == 0 && slot == 0, p0[c], p1[c], p2[c]);
+        else { p0[c] = gcoef[cg * 8 + c]; p1[c] = gcoef[32 + cg * 8 + c]; p2[c] = gcoef[64 + cg * 8 + c]; }
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
     }
@@ -367,20 +369,22 @@ struct LatentFwdArgs {
     float* mu; float* lv; float* z; double* accum;  // accum[1] += sum(1 + lv - mu^2 - exp(lv))
     int B, L;
 };
-__global__ void latent_fwd_kernel(LatentFwdArgs a) {   // 8 lanes per (b,l): split-K slabs summed in parallel
+constexpr int LAT_LANES = 32;   // lanes per (b,l): the split-K slabs are summed in parallel, all loads of a lane in flight
+__global__ void latent_fwd_kernel(LatentFwdArgs a) {
     __shared__ float wred[4];
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LAT_LANES, sub = threadIdx.x & (LAT_LANES - 1);
     float term = 0.f;
     const bool ok = i < a.B * a.L;
     const int b = ok ? i / a.L : 0, l = ok ? i % a.L : 0;
     float m = 0.f, v = 0.f;
-    if (ok)
-        for (int s = sub; s < a.nslab; s += 8) {
-            m += a.slab[((size_t)s * a.B + b) * a.npad + l];
-            v += a.slab[((size_t)s * a.B + b) * a.npad + a.L + l];
-        }
+    if (ok) {
+        const float* p = a.slab + (size_t)b * a.npad + l;
+        const size_t ss = (size_t)a.B * a.npad;
+#pragma unroll 4
+        for (int s = sub; s < a.nslab; s += LAT_LANES) { m += p[s * ss]; v += p[s * ss + a.L]; }
+    }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { m += __shfl_xor(m, o, 64); v += __shfl_xor(v, o, 64); }
+    for (int o = 1; o < LAT_LANES; o <<= 1) { m += __shfl_xor(m, o, 64); v += __shfl_xor(v, o, 64); }
     if (ok && sub == 0) {
         m += a.bmu[l]; v += a.bvar[l];
         const float sd = expf(0.5f * v);                      // models.py:181
@@ -390,7 +394,7 @@ __global__ void latent_fwd_kernel(LatentFwdArgs a) {   // 8 lanes per (b,l): spl
     term = wave_sum(term);
     if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = term;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&a.accum[1], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
+    if (threadIdx.x == 0) unsafeAtomicAdd(&a.accum[(blockIdx.x & (STAT_R - 1)) * 8 + 1], (double)(wred[0] + wred[1] + wred[2] + wred[3]));
 }
 
 // ELBO scalars (models.py:216-225): loss = bce + kld_weight*kld ; kld_loss reported with flipped sign.
@@ -426,15 +430,19 @@ struct LatentBwdArgs {
     float* dlat;                          // [B][2L]: dmu | dlv
     int B, L; float kld_weight; int add_kl;
 };
-__global__ void latent_bwd_kernel(LatentBwdArgs a) {   // 8 lanes per (b,l)
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+__global__ void latent_bwd_kernel(LatentBwdArgs a) {   // LAT_LANES lanes per (b,l)
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LAT_LANES, sub = threadIdx.x & (LAT_LANES - 1);
     const bool ok = i < a.B * a.L;
     const int b = ok ? i / a.L : 0, l = ok ? i % a.L : 0;
     float d = 0.f;
-    if (ok)
-        for (int s = sub; s < a.nslab; s += 8) d += a.slab[((size_t)s * a.B + b) * a.npad + l];
+    if (ok) {
+        const float* p = a.slab + (size_t)b * a.npad + l;
+        const size_t ss = (size_t)a.B * a.npad;
+#pragma unroll 4
+        for (int s = sub; s < a.nslab; s += LAT_LANES) d += p[s * ss];
+    }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) d += __shfl_xor(d, o, 64);
+    for (int o = 1; o < LAT_LANES; o <<= 1) d += __shfl_xor(d, o, 64);
     if (!ok || sub != 0) return;
     if (a.gz) d += a.gz[i];
     const float gs = a.gscale ? a.gscale[0] : 1.f;

@@ -94,7 +94,7 @@ struct vae_ctx {
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
     hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, knob_rev, walk_dir, bwd_dirty, bwd_half_done;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, knob_rev, knob_lean, walk_dir, bwd_dirty, bwd_half_done;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
@@ -162,7 +162,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 2048; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->knob_lean = 1; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->bwd_half_done = 0; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
@@ -228,8 +228,12 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
         ok = c->slab != nullptr;
         for (int i = 0; i < vae_ctx::NSIDE && ok; ++i) { c->side_slab[i] = dalloc<float>(c, slab); ok = c->side_slab[i] != nullptr; }
         if (ok) {
+            // side-stream priority: VAE_SIDE_PRIORITY=low|high (default: the device's default priority)
+            int prio_least = 0, prio_greatest = 0, side_prio = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            if (const char* e = getenv("VAE_SIDE_PRIORITY")) side_prio = !strcmp(e, "low") ? prio_least : !strcmp(e, "high") ? prio_greatest : 0;
             for (int i = 0; i < vae_ctx::NSIDE && ok; ++i)
-                ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+                ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, side_prio) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < vae_ctx::NFORK && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) == hipSuccess;
             if (ok) ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess &&
                          hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking) == hipSuccess &&
@@ -261,6 +265,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_lay22_min_nt")) { c->knob_lay22_min_nt = value; return 0; }
     if (!strcmp(name, "knob_conv1_grid")) { c->knob_conv1_grid = value; return 0; }
     if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
+    if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { g_wgrad_wide = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide_wgs")) { g_wgrad_wide_wgs = std::min(value, 1024); return 0; }
@@ -691,6 +696,10 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         SideFork f = fork_side(c, st);
         if (f.rc) return f.rc;
         if (pack_weights<T>(c, params, f.st)) return -1;
+        if (!eps && (c->knob_lean & 1)) {   // the reparameterisation noise is input-independent: drawn beside the first conv, not in the latent chain
+            hipLaunchKernelGGL(counter_normal_kernel, dim3((B * L + 255) / 256), dim3(256), 0, f.st, c->eps, (long)B * L, (unsigned long long)seed, 5ULL);
+            LAUNCH_CHECK("counter_normal_kernel");
+        }
         if (c->use_side_stream) HIP_CHECK_RET(hipEventRecord(c->ev_pack, f.st));
     }
     {
@@ -722,14 +731,14 @@ static int forward_impl(vae_ctx* c, const float* x, int B, const float* params, 
         int nsplit;
         if (launch_dense<T>(c, a, &nsplit, st)) return -1;
         if (eps) HIP_CHECK_RET(hipMemcpyAsync(c->eps, eps, (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
-        else {
+        else if (!(c->knob_lean & 1)) {
             hipLaunchKernelGGL(counter_normal_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, c->eps, (long)B * L, (unsigned long long)seed, 5ULL);
             LAUNCH_CHECK("counter_normal_kernel");
         }
         LatentFwdArgs la;
         la.slab = c->slab; la.nslab = nsplit; la.npad = c->npad_fc; la.bmu = params + c->poff[17]; la.bvar = params + c->poff[19];
         la.eps = c->eps; la.mu = mu; la.lv = lv; la.z = z; la.accum = c->accum; la.B = B; la.L = L;
-        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, la);
+        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B * L * LAT_LANES + 255) / 256), dim3(256), 0, st, la);
         LAUNCH_CHECK("latent_fwd_kernel");
     }
     return decode_impl<T>(c, z, B, params, bn_running, nbt, train, x, xhat, st);
@@ -859,7 +868,7 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         LatentBwdArgs lb;
         lb.slab = c->slab; lb.nslab = nsplit; lb.npad = c->npad_di; lb.mu = c->mu; lb.lv = c->lv; lb.eps = c->eps; lb.gscale = gscale;
         lb.gmu = g_mu; lb.glv = g_lv; lb.gz = g_z; lb.dlat = c->dlat; lb.B = B; lb.L = L; lb.kld_weight = kld_weight; lb.add_kl = add_kl;
-        hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L * 8 + 255) / 256), dim3(256), 0, st, lb);
+        hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L * LAT_LANES + 255) / 256), dim3(256), 0, st, lb);
         LAUNCH_CHECK("latent_bwd_kernel");
         SideFork f = fork_side(c, st);
         if (f.rc) return f.rc;
@@ -916,7 +925,8 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
     }
     {
         c->tag = kLayerTag[0];
-        if (bn_finalize_now(c, make_fuse_bwd(c, 0, params, grads), st)) return -1;
+        BnFuse fb0 = make_fuse_bwd(c, 0, params, grads);
+        if (!c->use_fused_bn || !(c->knob_lean & 2)) { if (bn_finalize_now(c, fb0, st)) return -1; fb0.mode = BNF_NONE; }
         const long P = (long)B * (H / 2) * (H / 2);
         const int grid = (int)std::min<long>((P + 63) / 64, 512);
         // last link of the chain: stays on the caller's stream (a side stream would only add an event round trip)
@@ -924,7 +934,7 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         {
             ProfScope ps(c, "conv1_wgrad", 4.0 * B * H * H + (double)sizeof(T) * 64.0 * P, 2.0 * 9 * 32 * P, f.st);
             hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, f.st, x, reinterpret_cast<const T*>(c->lay[0].dz),
-                               reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, f.slab, B, H, H);
+                               reinterpret_cast<const T*>(c->lay[0].y), c->lay[0].block + LC_P0 * 32, f.slab, B, H, H, fb0);
             LAUNCH_CHECK("conv1_wgrad_kernel");
         }
         if (launch_reduce(f.slab, grid, 288, grads + c->poff[0], 32, 1, f.st, c)) return -1;
@@ -978,6 +988,20 @@ extern "C" int vae_decode(vae_ctx* c, const float* z, int B, const float* params
 extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
     if (!c || !c->B) return vae_set_error("vae_loss", "no forward");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->accum, out3,
+                       1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight, STAT_R);
+    LAUNCH_CHECK("loss_finalize_kernel");
+    return 0;
+}
+
+// Same scalars, computed beside the backward instead of in front of it: enqueued on one of the context's side streams
+// (ordered after `stream`), so out3 is ordered into the caller's stream by the NEXT vae_backward / vae_backward_part
+// on this context - for callers that only read the ELBO after the backward (train.py:644-674 reads it after the step).
+extern "C" int vae_loss_deferred(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
+    if (!c || !c->B) return vae_set_error("vae_loss_deferred", "no forward");
+    if (!c->trained) return vae_set_error("vae_loss_deferred", "needs a train-mode forward (a backward must follow)");
+    SideFork f = (c->knob_lean & 4) ? fork_side(c, (hipStream_t)stream) : SideFork{(hipStream_t)stream, c->slab, 0};
+    if (f.rc) return f.rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, f.st, c->accum, out3,
                        1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight, STAT_R);
     LAUNCH_CHECK("loss_finalize_kernel");
     return 0;
@@ -1046,7 +1070,7 @@ extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, 
                               const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
                               float weight_decay, int step, float* xhat, float* mu, float* lv, float* z, float* out3, vae_stream_t stream) {
     if (vae_forward(c, x, B, params, bn_running, nbt, eps, seed, 1, xhat, mu, lv, z, stream)) return -1;
-    if (vae_loss(c, kld_weight, out3, stream)) return -1;
+    if (vae_loss_deferred(c, kld_weight, out3, stream)) return -1;
     if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
     if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, 1.f, step, stream)) return -1;
     return 0;

@@ -475,7 +475,8 @@ class VanillaVAE(nn.Module):
             eps = torch.randn(x.shape[0], self.latent_dim, device=x.device, dtype=torch.float32)
         xhat, mu, lv, z, _ = self._run_forward(x, eps, train=True, want_pre=False)
         out3 = torch.empty(3, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().vae_loss(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss")
+        # the ELBO scalars are only read after the step: finalised beside the backward (joined by it), not in front of it
+        _lib.check(_lib.lib().vae_loss_deferred(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss_deferred")
         self._bwd_kld_weight = float(self.kld_weight)
         last = self._last
         for part in ((0,) if on_decoder_grads is None else (1, 2)):
