@@ -167,7 +167,8 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
  *                           what its producer wrote last finds it in L2 / the memory-side cache
- *   knob_lean [7]           launches kept off the critical chain (bit 0 reparameterisation noise drawn beside the first conv,
+ *   knob_wgrad_mid8 [0]     eight waves on the 64x32-channel weight-gradient tile (measured slower; diagnostics)
+ *   knob_lean [1]           launches kept off the critical chain (bit 0 reparameterisation noise drawn beside the first conv,
  *                           1 BatchNorm backward of encoder block 0 inside its weight-gradient kernel, 2 vae_loss_deferred
  *                           really on a side stream)
  *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks

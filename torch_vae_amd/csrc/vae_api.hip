@@ -136,7 +136,7 @@ extern "C" void vae_destroy(vae_ctx* c) {
 }
 extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_bytes : 0; }
 
-static int g_wgrad_wgs = 128, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1, g_wgrad_wide_wgs = 128, g_wgrad_small_wgs = 1024;
+static int g_wgrad_wgs = 128, g_wgrad_cap_mb = 48, g_wgrad_tile = 1, g_wgrad_wide = 1, g_wgrad_wide_wgs = 128, g_wgrad_small_wgs = 1024, g_wgrad_mid8 = 0;
 // workgroup targets: weight gradients run beside the input-gradient chain; on a saturated GPU (large batch x image) few
 // workgroups keep them out of its way (-4 % step time at the bench workload), a small problem wants them everywhere.
 //   // wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (bf16 prefetching kernel)
@@ -268,6 +268,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
     if (!strcmp(name, "knob_wgrad_tile")) { g_wgrad_tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { g_wgrad_wide = value; return 0; }
+    if (!strcmp(name, "knob_wgrad_mid8")) { g_wgrad_mid8 = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide_wgs")) { g_wgrad_wide_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_wgs")) { g_wgrad_wgs = std::min(value, 1024); return 0; }
     if (!strcmp(name, "knob_wgrad_cap_mb")) { g_wgrad_cap_mb = std::min(value, 48); return 0; }
@@ -410,7 +411,8 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     a.n_tiles = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y; a.tiles_per_split = tps;
     a.slab = slab_buf; a.use_tr16 = c->use_tr16; a.rev = (c->knob_rev >> 3) & 1;
     a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
-    const int nthr = WA == 4 ? 512 : 256, maxg = (5 * WB * 256 + nthr - 1) / nthr;
+    const bool mid8 = g_wgrad_mid8 && WA == 2 && WB == 1 && c->use_pipelined && sizeof(T) == 2;   // eight waves on the 64x32-channel tile
+    const int nthr = (WA == 4 || mid8) ? 512 : 256, maxg = (5 * WB * 256 + nthr - 1) / nthr;
     const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
                        (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16) +
                        ((c->use_pipelined && sizeof(T) == 2) ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)maxg * nthr) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*threads)
@@ -429,6 +431,12 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
         if constexpr (sizeof(T) == 2) {
             if (convt) { if (set_lds(wgrad_kernel<T, 4, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, true, true, 8>), grid, dim3(512), lds, st, a); }
             else { if (set_lds(wgrad_kernel<T, 4, 1, false, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, false, true, 8>), grid, dim3(512), lds, st, a); }
+        }
+    }
+    else if (mid8) {
+        if constexpr (sizeof(T) == 2) {
+            if (convt) { if (set_lds(wgrad_kernel<T, 2, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 2, 1, true, true, 8>), grid, dim3(512), lds, st, a); }
+            else { if (set_lds(wgrad_kernel<T, 2, 1, false, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 2, 1, false, true, 8>), grid, dim3(512), lds, st, a); }
         }
     }
     else if (WA == 2 && WB == 2) { if (pre) WG_KIND(2, 2, true) else WG_KIND(2, 2, false) }
