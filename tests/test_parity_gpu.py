@@ -468,7 +468,10 @@ def test_execution_options_do_not_change_results(dtype):
         return res
 
     base = run({})
-    for opts in ({"use_side_stream": 0}, {"use_fused_bn": 0}, {"use_side_stream": 0, "use_fused_bn": 0}):
+    # knob_lean: which small launches stay off the caller's stream (7: also BatchNorm backward of block 0 inside its
+    # weight-gradient kernel and the ELBO scalars on a side stream); knob_wgrad_mid8 is library-wide, reset below
+    for opts in ({"use_side_stream": 0}, {"use_fused_bn": 0}, {"use_side_stream": 0, "use_fused_bn": 0}, {"knob_lean": 7},
+                 {"knob_lean": 0}, {"knob_wgrad_mid8": 1}, {"knob_wgrad_mid8": 0}):
         got = run(opts)
         for a, b in zip(got, base):
             for u, v in zip(a, b):
