@@ -98,7 +98,7 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     // last forward
     int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
-    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_convout_bwd_grid, knob_nt_max, knob_pipe_max_cout, knob_ablate_b; long long* dbg_buf; char dbg_tag[32]; int dbg_epi; int64_t ws_bytes;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_convout_bwd_grid, knob_down_per_cu, knob_nt_max, knob_pipe_max_cout, knob_ablate_b; long long* dbg_buf; char dbg_tag[32]; int dbg_epi; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; }; std::vector<ProfRec> prof_recs;
@@ -162,7 +162,7 @@ static size_t wgrad_slab_floats(int B, int Hs, int Ws, int CA, int CB, int* nspl
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 1536; c->knob_convout_bwd_grid = 1536; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->knob_lean = 1; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 4; c->knob_convout_grid = 1536; c->knob_convout_bwd_grid = 1536; c->knob_down_per_cu = 2; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 4; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->knob_lean = 1; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->bwd_half_done = 0; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
@@ -255,6 +255,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_pipelined")) { c->use_pipelined = value; return 0; }
     if (!strcmp(name, "knob_up_per_cu")) { c->knob_up_per_cu = value; return 0; }
     if (!strcmp(name, "knob_convout_grid")) { c->knob_convout_grid = value; return 0; }
+    if (!strcmp(name, "knob_down_per_cu")) { c->knob_down_per_cu = std::max(1, value); return 0; }
     if (!strcmp(name, "knob_convout_bwd_grid")) { c->knob_convout_bwd_grid = value; return 0; }
     if (!strcmp(name, "knob_nt_max")) { c->knob_nt_max = value; return 0; }
     if (!strcmp(name, "knob_pipe_max_cout")) { c->knob_pipe_max_cout = value; return 0; }
@@ -363,7 +364,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     if (c->knob_ablate_b) a.two_src |= 2;
     a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
     if ((a.two_src & 1) && a.slope != 1.f) return vae_set_error("conv_pipe", "gradient operands are loaded without LeakyReLU (slope must be 1)");
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? 2 : c->knob_up_per_cu, (160 * 1024) / lds));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(is_down ? c->knob_down_per_cu : c->knob_up_per_cu, (160 * 1024) / lds));
     const int n_wg_pairs = wv ? ((n_mt + 3) / 4) * ntn : n_pairs;    // workgroup-level work items
     int grid = std::min(n_wg_pairs, 256 * ((c->knob_bwd_per_cu > 0 && a.epi != EPI_FWD) ? std::min(per_cu, c->knob_bwd_per_cu) : per_cu));
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
