@@ -33,6 +33,10 @@ typedef void* vae_stream_t; /* hipStream_t */
 #define VAE_NUM_BN 8
 #define VAE_DTYPE_F32 0  /* f32 storage, f32-input MFMA: exact f32 FMA-chain arithmetic */
 #define VAE_DTYPE_BF16 1 /* bf16 activation/weight storage, bf16 MFMA, f32 accumulate/statistics */
+#define VAE_DTYPE_F16 2  /* f16 activation/weight storage, f16 MFMA, f32 accumulate; KL / BCE / BatchNorm statistics in
+                          * f32 / f64 as in the other modes.  Stored gradients are scaled by a power of two chosen per
+                          * forward (the BCE mean makes dL/dlogit ~ 1/(B*H*W), below the f16 range) and every parameter
+                          * gradient is unscaled on output, so callers see ordinary gradients. */
 
 const char* vae_last_error(void);
 int vae_abi_version(void);
@@ -118,6 +122,29 @@ int vae_backward_part(vae_ctx* ctx, const float* x, const float* params, float* 
  * stream at the end of part 2, so the collective overlaps the encoder half without any host-side handshake. */
 int vae_comm_stream(vae_ctx* ctx, vae_stream_t stream, vae_stream_t* out);
 
+/* ---- data parallel: one process per GPU, gradients exchanged over RCCL (xGMI inside a node) -------------------------
+ * The reference has no exchange step: it only scales the learning rate and the sample counters by
+ * WORLD_SIZE (train.py:165-166, 201, 663).  These entry points are the gradient all-reduce north_star asks for, issued
+ * by the library itself so that backward kernels, collective and AdamW share streams without a framework hand-off.
+ * vae_comm_unique_id: rank 0 fills a VAE_COMM_ID_BYTES id; the host distributes it over any channel it has
+ * (torch.distributed's store / broadcast, MPI, a file); every rank then calls vae_comm_init with the device it will run on
+ * current.  The communicator belongs to the context (released by vae_comm_destroy / vae_destroy). */
+#define VAE_COMM_ID_BYTES 128
+int vae_comm_unique_id(void* id /*[VAE_COMM_ID_BYTES]*/);
+int vae_comm_init(vae_ctx* ctx, int rank, int world, const void* id /*[VAE_COMM_ID_BYTES]*/);
+int vae_comm_world(const vae_ctx* ctx); /* world size of the context's communicator, 0 if none */
+int vae_comm_destroy(vae_ctx* ctx);
+/* In-place all-reduce over ranks of `nranges` ranges [offsets[i], offsets[i]+sizes[i]) of the flat f32 gradient buffer,
+ * as one RCCL group enqueued on `stream`: the caller's stream (ordered after the backward by the stream itself) or the
+ * context's communication stream (vae_comm_stream) for the decoder bucket between vae_backward_part 1 and 2.
+ * average != 0 leaves the MEAN over ranks (what a data-parallel caller expects in .grad); 0 the sum. */
+int vae_allreduce_grads(vae_ctx* ctx, float* grads, int nranges, const int64_t* offsets, const int64_t* sizes, int average,
+                        vae_stream_t stream);
+/* Identical replicas before the first step: broadcast rank `root`'s flat parameters, BatchNorm running statistics and
+ * num_batches_tracked (NULL to skip the latter two) over the context's communicator. */
+int vae_broadcast_state(vae_ctx* ctx, float* params, float* bn_running, int64_t* num_batches_tracked, int root,
+                        vae_stream_t stream);
+
 /* torch.optim.AdamW.step (train.py:228,656) on up to two contiguous ranges of the flat
  * buffers (the encoder and decoder groups of train.py:210-225), each with the lr and beta1
  * OneCycleLR set for this step (train.py:233-238,659).  step is 1-based. */
@@ -168,6 +195,7 @@ int vae_selftest_tr16(vae_stream_t stream);
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
  *                           what its producer wrote last finds it in L2 / the memory-side cache
  *   knob_wgrad_mid8 [0]     eight waves on the 64x32-channel weight-gradient tile (measured slower; diagnostics)
+ *   knob_wgrad_force_simple [0]  take the 64-bit-offset weight-gradient kernel (the fallback for tensors >= 4 GiB) at any size
  *   knob_lean [1]           launches kept off the critical chain (bit 0 reparameterisation noise drawn beside the first conv,
  *                           1 BatchNorm backward of encoder block 0 inside its weight-gradient kernel, 2 vae_loss_deferred
  *                           really on a side stream)

@@ -42,7 +42,14 @@ CASES = [
     ("G_h64_l64_b8", 64, 64, 8, 2, 10, 1.0, True, 7),
     ("G_h128_l16_b2", 128, 16, 2, 1, 10, 1.0, True, 8),
     ("G_h128_l128_b2", 128, 128, 2, 1, 10, 4.0, True, 9),
+    # round 2: the remaining BASELINE.json shapes (configs[2]: 256x256 latent 64; configs[4]: 128x128 latent 128, beta 1/16)
+    # and the reference's own default latent size 10 (train.py:875-877), which is not a multiple of 4
+    ("G_h256_l64_b2", 256, 64, 2, 1, 10, 1.0, True, 10),
+    ("G_h128_l128_b2_k1", 128, 128, 2, 1, 10, 1.0, True, 11),
+    ("G_h128_l128_b2_k16", 128, 128, 2, 1, 10, 16.0, True, 12),
+    ("R_l10_b8", 32, 10, 8, 2, 10, 1.0, False, 13),
 ]
+ROUND1 = 9   # the first nine cases are the round-1 fixtures (not regenerated unless --all)
 
 
 def import_reference():
@@ -104,7 +111,7 @@ def build_model(models, H, L, generalised, kld_weight, params, dtype):
     return m
 
 
-def run_case(models, train, case, dtype):
+def run_case(models, train, case, dtype, checkpoint_to=None):
     name, H, L, B, steps, total_steps, kw, gen, seed = case
     params = vo.init_params(L, H, seed, gen, np.float64)
     model = build_model(models, H, L, gen, kw, params, dtype)
@@ -170,6 +177,30 @@ def run_case(models, train, case, dtype):
             out["epoch_loss"] = np.array(res["loss"])
             out["total_step"] = np.array(total_step)
             out["n_samples_seen"] = np.array(n_seen)
+        if checkpoint_to is not None:
+            # N2: a checkpoint written by the reference's own utils.safe_save_model (utils.py:311-351) with the modules
+            # train.py:444-460 passes, then two more steps of the reference's loop from that state (the trajectory a
+            # resumed run must continue)
+            import utils as ref_utils
+            cfg_ck = Namespace(checkpoint_path=checkpoint_to, global_rank=1, lr=lr, batch_size=B)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_utils.safe_save_model({"encoder": model.encoder, "decoder": model.decoder, "optimizer": optimizer,
+                                           "scheduler": scheduler}, checkpoint_to, config=cfg_ck, epoch=2, total_step=steps,
+                                          n_samples_seen=steps * B, best_epoch=0)
+            nxt = []
+            xs2 = [torch.from_numpy(vo.synth_pianoroll(B, H, seed * 1000 + s)).to(dtype) for s in range(steps, steps + 2)]
+            queue.extend(torch.from_numpy(vo.counter_normal(B * L, seed * 1000 + s, 5).reshape(B, L)).to(dtype) for s in range(steps, steps + 2))
+
+            def crit2(o_):
+                r = model.loss(o_)
+                nxt.append([r["loss"].item(), r["reconstruction_loss"].item(), r["kld_loss"].item()])
+                return r
+
+            cfg = Namespace(log_wandb=False, print_interval=1000, log_interval=1000, freeze_encoder=False, world_size=1, global_rank=0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                train.train_one_epoch(cfg, model, optimizer, scheduler, crit2, [(x, torch.zeros(B, dtype=torch.long)) for x in xs2],
+                                      device="cpu", epoch=3, total_step=steps, n_samples_seen=steps * B)
+            out["resumed_losses"] = np.array(nxt, dtype=np.float64)
     finally:
         torch.randn_like = orig
     out["losses"] = np.array(losses, dtype=np.float64)
@@ -181,6 +212,30 @@ def run_case(models, train, case, dtype):
     for n, b in model.named_buffers():
         out["buf/" + n] = b.detach().double().numpy()
     return out
+
+
+def evaluate_fixture(models):
+    """N3: the reference's evaluation.evaluate (evaluation.py:12-113) on a two-batch loader whose dataset is one sample
+    shorter than the batches (the DistributedSampler-padding trim at :88-95), eval mode, fresh running statistics."""
+    import evaluation as ref_eval
+    H, L, B, seed, n_samples = 32, 16, 4, 21, 7
+    params = vo.init_params(L, H, seed, False, np.float64)
+    model = build_model(models, H, L, False, 1.0, params, torch.float32)
+
+    class Loader(list):
+        pass
+
+    loader = Loader((torch.from_numpy(vo.synth_pianoroll(B, H, seed * 1000 + i)), torch.zeros(B, dtype=torch.long)) for i in range(2))
+    loader.dataset = range(n_samples)
+    queue = [torch.from_numpy(vo.counter_normal(B * L, seed * 1000 + i, 5).reshape(B, L)).float() for i in range(2)]
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: queue.pop(0).to(t.dtype)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = ref_eval.evaluate(loader, model, "cpu", verbosity=0)
+    finally:
+        torch.randn_like = orig
+    return {k: np.array(float(v)) for k, v in res.items()}
 
 
 def bce_fixture():
@@ -211,14 +266,22 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     models, train = import_reference()
-    for case in CASES:
+    cases = CASES if "--all" in sys.argv else CASES[ROUND1:]
+    for case in cases:
         for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
             out = run_case(models, train, case, dtype)
             path = os.path.join(HERE, f"{case[0]}_{tag}.npz")
             np.savez_compressed(path, **out)
             print(case[0], tag, "loss", out["losses"][0], os.path.getsize(path), "bytes")
-    np.savez_compressed(os.path.join(HERE, "bce_edges.npz"), **bce_fixture())
-    np.savez_compressed(os.path.join(HERE, "onecycle.npz"), **onecycle_fixture())
+    # N2: reference-written checkpoint (f32, after the 3 steps of R_b4_k1) + the losses of the two steps that follow it
+    ck = os.path.join(HERE, "ckpt_R_b4_k1_f32.pt")
+    out = run_case(models, train, CASES[0], torch.float32, checkpoint_to=ck)
+    np.savez_compressed(os.path.join(HERE, "ckpt_R_b4_k1_f32_next.npz"), resumed_losses=out["resumed_losses"], losses=out["losses"])
+    print("checkpoint", os.path.getsize(ck), "bytes; resumed losses", out["resumed_losses"][:, 0])
+    np.savez_compressed(os.path.join(HERE, "evaluate_R.npz"), **evaluate_fixture(models))
+    if "--all" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "bce_edges.npz"), **bce_fixture())
+        np.savez_compressed(os.path.join(HERE, "onecycle.npz"), **onecycle_fixture())
 
 
 if __name__ == "__main__":

@@ -160,3 +160,78 @@ def test_allreduce_helper_ranges_cover_optimised_groups():
     assert eo == 0 and en >= 388800 and dn >= 387744 and do > eo + en
     with pytest.raises(ValueError):
         m.group_range("nonexistent")
+
+
+_DP_HOST_WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from torch_vae_amd import train
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+class FlatModel:
+    # the flat-buffer surface of VanillaVAE that the data-parallel host code touches (no kernels on a CPU box)
+    def __init__(self):
+        g = torch.Generator().manual_seed(100 + rank)
+        self._flat = torch.randn(64, generator=g); self._bnflat = torch.randn(8, generator=g); self._nbt = torch.full((8,), rank, dtype=torch.int64)
+        self._g = torch.arange(64, dtype=torch.float32) * (rank + 1)
+    def flat_grads(self): return self._g
+    def flat_parameters(self): return self._flat
+    def group_range(self, prefix): return {"encoder": (0, 16), "decoder": (32, 16)}[prefix]
+    def library_comm_world(self): return 0
+    def comm_stream(self): raise AssertionError("no stream hand-off on the in-line path")
+
+m = FlatModel()
+train.sync_initial_state(m)
+ref = [t.clone() for t in (m._flat, m._bnflat, m._nbt)]
+for t in ref: dist.broadcast(t, 0)
+assert all(torch.equal(a, b) for a, b in zip(ref, (m._flat, m._bnflat, m._nbt))) and int(m._nbt[0]) == 0
+train.allreduce_gradients(m)
+base = torch.arange(64, dtype=torch.float32)
+want = base * (1 + 2) / 2            # mean of rank 0's (x1) and rank 1's (x2) gradients
+assert torch.equal(m._g[0:16], want[0:16]) and torch.equal(m._g[32:48], want[32:48])
+assert torch.equal(m._g[16:32], base[16:32] * (rank + 1)) and torch.equal(m._g[48:], base[48:] * (rank + 1))   # never-optimised ranges stay local
+print("DP_HOST_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_host_logic_world2_gloo(tmp_path):
+    """torch_vae_amd.train's own data-parallel host code with world_size 2 over gloo on CPU: the initial broadcast makes the
+    replicas identical, the exchange leaves the MEAN of the optimised ranges in the gradient buffer and touches nothing else."""
+    script = tmp_path / "dp_host_worker.py"
+    script.write_text(_DP_HOST_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("DP_HOST_OK") == 2
+
+
+def test_checkpoint_helpers_format_and_atomicity(tmp_path):
+    """utils.safe_save_model keeps the reference's FORMAT (utils.py:311-351: one dict of state_dicts + extras + config) and
+    never leaves a partial file; should_save reproduces the reference's rank gate (train.py:444) unless told to fix it."""
+    from argparse import Namespace
+    from torch_vae_amd import utils
+    lin = torch.nn.Linear(3, 2)
+    cfg = Namespace(checkpoint_path=str(tmp_path / "a" / "b" / "ckpt.pt"), model_output_dir=str(tmp_path), global_rank=0)
+    path = utils.safe_save_model({"encoder": lin}, config=cfg, epoch=7, total_step=11)
+    assert path == cfg.checkpoint_path and os.listdir(os.path.dirname(path)) == ["ckpt.pt"]      # no temporary left behind
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"encoder", "epoch", "total_step", "config"} and ck["epoch"] == 7 and torch.equal(ck["encoder"]["weight"], lin.weight)
+
+    class Boom(torch.nn.Module):
+        def state_dict(self, *a, **k):
+            return {"w": (lambda: 0)}            # unpicklable: torch.save raises mid-write
+    with pytest.raises(Exception):
+        utils.safe_save_model({"encoder": Boom()}, path)
+    assert os.listdir(os.path.dirname(path)) == ["ckpt.pt"] and torch.load(path, weights_only=False)["epoch"] == 7   # old file intact
+    with pytest.raises(ValueError):
+        utils.safe_save_model({"encoder": lin})
+    assert utils.should_save(cfg) is False and utils.should_save(cfg, fix_rank_gate=True) is True      # rank 0 never saves in the reference
+    cfg.global_rank = 1
+    assert utils.should_save(cfg) is True and utils.should_save(cfg, fix_rank_gate=True) is False
+    cfg.model_output_dir = None
+    assert utils.should_save(cfg) is False

@@ -6,20 +6,9 @@ import numpy as np
 import pytest
 
 from oracle import vae_oracle as vo
+from tests.util import CASES
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = {
-    # name: H, L, B, steps, total_steps, kld_weight, generalised, seed
-    "R_b4_k1": (32, 16, 4, 3, 10, 1.0, False, 1),
-    "R_b32_k1": (32, 16, 32, 20, 200, 1.0, False, 2),
-    "R_b32_k4": (32, 16, 32, 2, 10, 4.0, False, 3),
-    "R_b32_k16": (32, 16, 32, 2, 10, 16.0, False, 4),
-    "R_b256_k1": (32, 16, 256, 2, 10, 1.0, False, 5),
-    "G_h64_l16_b4": (64, 16, 4, 2, 10, 1.0, True, 6),
-    "G_h64_l64_b8": (64, 64, 8, 2, 10, 1.0, True, 7),
-    "G_h128_l16_b2": (128, 16, 2, 1, 10, 1.0, True, 8),
-    "G_h128_l128_b2": (128, 128, 2, 1, 10, 4.0, True, 9),
-}
 # conv biases that feed a train-mode BatchNorm have an analytically zero gradient;
 # the reference produces rounding noise there which AdamW then normalises, so these
 # parameters are excluded from post-step parameter comparisons.

@@ -5,9 +5,13 @@ fixtures generated from the reference.  Tolerances:
                     one pre-activation within rounding distance of 0 (binary inputs make exact ties
                     common) flips a derivative and moves a whole gradient by ~1e-3, so gradient
                     checks allow 5e-3 ("kink ties").
-  bf16 kernel mode: ELBO scalars <= 1e-2 relative (reference's own bf16 autocast gap is 4.4e-3,
-                    SURVEY.md H4); gradients are checked by direction (cosine) and norm.
+  bf16 kernel mode: ELBO scalars <= 1e-2 relative (reference's own bf16 autocast gap is 4.4e-3, SURVEY.md H4);
+                    gradients per tensor rel-L2 <= GRAD_TOL["bf16"] against the fp64 oracle.
+  f16 kernel mode : ELBO scalars <= 2e-3, gradients rel-L2 <= GRAD_TOL["f16"] (10 mantissa bits instead of 7).
+The 16-bit bounds are what the kernels measure on MI355X (every run appends its measured gaps to
+gpurun_out/parity_report.jsonl) plus headroom, not a cosine: a gradient within them has the right direction AND size.
 """
+import json
 import os
 
 import numpy as np
@@ -15,23 +19,25 @@ import pytest
 import torch
 
 from oracle import vae_oracle as vo
-from tests.util import PRE_BN_BIAS, flat_grad_dict, load_params, make_model, perturbed_params, rel_l2
+from tests.util import CASES, PRE_BN_BIAS, flat_grad_dict, load_params, make_model, perturbed_params, rel_l2
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ELBO_TOL = {"f32": 1e-4, "bf16": 1e-2, "f16": 2e-3}
+GRAD_TOL = {"f32": 5e-3, "bf16": 6e-2, "f16": 1.5e-2}     # per-tensor rel-L2 vs the fp64 oracle
+FWD_TOL = {"f32": 1e-4, "bf16": 2e-2, "f16": 3e-3}        # xhat rel-L2
 
-CASES = {
-    # name: H, L, B, steps, total_steps, kld_weight, generalised, seed   (same table as the fixtures)
-    "R_b4_k1": (32, 16, 4, 3, 10, 1.0, False, 1),
-    "R_b32_k1": (32, 16, 32, 20, 200, 1.0, False, 2),
-    "R_b32_k4": (32, 16, 32, 2, 10, 4.0, False, 3),
-    "R_b32_k16": (32, 16, 32, 2, 10, 16.0, False, 4),
-    "R_b256_k1": (32, 16, 256, 2, 10, 1.0, False, 5),
-    "G_h64_l16_b4": (64, 16, 4, 2, 10, 1.0, True, 6),
-    "G_h64_l64_b8": (64, 64, 8, 2, 10, 1.0, True, 7),
-    "G_h128_l16_b2": (128, 16, 2, 1, 10, 1.0, True, 8),
-    "G_h128_l128_b2": (128, 128, 2, 1, 10, 4.0, True, 9),
-}
+
+def report(**kw):
+    """Measured gaps of the 16-bit modes, kept under gpurun_out/ (scratch) so the bounds above can be audited."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
 
 
 def case_inputs(name, step):
@@ -75,11 +81,16 @@ def test_f32_step0_matches_reference_fixture(name):
 
 
 @pytest.mark.parametrize("cfg", [(32, 16, 5, False), (32, 16, 33, False), (64, 32, 3, True), (128, 16, 2, True),
-                                 (32, 16, 1, False), (64, 8, 1, True), (32, 128, 7, True), (256, 16, 1, True), (32, 4, 130, False)])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+                                 (32, 16, 1, False), (64, 8, 1, True), (32, 128, 7, True), (256, 16, 1, True), (32, 4, 130, False),
+                                 # latent sizes whose padded widths are not a power-of-two number of 32-column blocks
+                                 # (npad 96 / 160 / 192: the dense kernel's N tiling) and sizes that are not a multiple of 4
+                                 (32, 40, 3, False), (32, 48, 5, False), (32, 80, 3, False), (32, 96, 4, False), (64, 160, 2, True),
+                                 (32, 10, 6, False), (64, 10, 2, True), (32, 1, 3, False), (32, 3, 9, False)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_every_tensor_against_oracle(cfg, dtype):
     """All gradients (full tensors) against the fp64 oracle, with non-trivial BN affine/bias values,
-    ragged batch sizes (not a multiple of any tile), batch 1, the smallest / largest latent sizes and image sizes."""
+    ragged batch sizes (not a multiple of any tile), batch 1, the smallest / largest latent sizes and image sizes,
+    the reference's default latent size 10 (train.py:875-877)."""
     H, L, B, gen = cfg
     p = perturbed_params(L, H, 17, gen)
     model = make_model(H, L, gen, dtype, p)
@@ -90,21 +101,20 @@ def test_every_tensor_against_oracle(cfg, dtype):
     lo = vo.loss(c)
     g = vo.backward(p, c)
     want = np.array([float(lo["loss"]), float(lo["reconstruction_loss"]), float(lo["kld_loss"])])
-    ftol, gtol = (1e-4, 5e-3) if dtype == "f32" else (1e-2, None)
-    np.testing.assert_allclose(np.array(out3.tolist()), want, rtol=ftol)
-    assert rel_l2(xhat.cpu().numpy(), c["output"]) < (1e-4 if dtype == "f32" else 2e-2)
-    assert rel_l2(model._last["mu"].cpu().numpy(), c["mu"]) < (1e-4 if dtype == "f32" else 3e-2)
+    got3 = np.array(out3.tolist())
     got = flat_grad_dict(model)
-    for n, v in got.items():
-        if n in PRE_BN_BIAS:
-            continue
-        ref = g[n].reshape(-1)
-        if dtype == "f32":
-            assert rel_l2(v, ref) < gtol, n
-        else:
-            cos = float(np.dot(v.astype(np.float64), ref) / (np.linalg.norm(v) * np.linalg.norm(ref) + 1e-30))
-            assert cos > 0.97, (n, cos)
-            assert 0.8 < np.linalg.norm(v) / np.linalg.norm(ref) < 1.25, n
+    gaps = {n: rel_l2(v, g[n].reshape(-1)) for n, v in got.items() if n not in PRE_BN_BIAS}
+    worst = max(gaps, key=gaps.get)
+    report(test="every_tensor", cfg=list(cfg), dtype=dtype, elbo_rel=float(np.abs(got3 / want - 1).max()),
+           xhat_rel_l2=rel_l2(xhat.cpu().numpy(), c["output"]), grad_rel_l2_max=gaps[worst], worst=worst)
+    np.testing.assert_allclose(got3, want, rtol=ELBO_TOL[dtype])
+    assert rel_l2(xhat.cpu().numpy(), c["output"]) < FWD_TOL[dtype]
+    assert rel_l2(model._last["mu"].cpu().numpy(), c["mu"]) < 1.5 * FWD_TOL[dtype]
+    # a single sample at the 2x2 bottleneck gives BatchNorm four values per channel: the f64 gradient itself is
+    # ill-conditioned there (near-zero variances), so the 16-bit bound is only meaningful from two samples up
+    tol = GRAD_TOL[dtype] * (4.0 if (dtype != "f32" and B * (H // 16) ** 2 < 16) else 1.0)
+    for n, gap in gaps.items():
+        assert gap < tol, (n, gap)
 
 
 def test_tr16_and_scalar_wgrad_agree():
@@ -618,3 +628,307 @@ def test_bench_two_rank_control_flow():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["roofline"]["achieved"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: every BASELINE.json configuration on the HIP path, the 16-bit modes gated at what they measure, the reference's
+# edge cases on the HIP kernels, fallbacks forced, N2/N3 pinned to reference-written fixtures
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["G_h256_l64_b2", "G_h128_l128_b2_k1", "G_h128_l128_b2_k16", "G_h128_l128_b2", "G_h128_l16_b2", "R_l10_b8"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_step0_against_reference_fixture(name, dtype):
+    """The 16-bit storage modes on the BASELINE shapes (configs[2]: 256x256 latent 64; configs[4]: 128x128 latent 128 at
+    beta 1 / 4 / 16) against the REFERENCE's fp64 outputs: measured gap reported, bounded by ELBO_TOL / GRAD_TOL."""
+    H, L, B, steps, total, kw, gen, seed = CASES[name]
+    gold = np.load(os.path.join(GOLD, f"{name}_f64.npz"))
+    model = make_model(H, L, gen, dtype, vo.init_params(L, H, seed, gen), kld_weight=kw)
+    x, eps = case_inputs(name, 0)
+    out3, xhat = model.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+    got = np.array(out3.tolist())
+    elbo_gap = float(np.abs(got / gold["losses"][0] - 1).max())
+    g = flat_grad_dict(model)
+    norm_gap = {n: abs(float(np.sqrt((v.astype(np.float64) ** 2).sum())) / float(gold["gradnorm/" + n]) - 1)
+                for n, v in g.items() if n not in PRE_BN_BIAS}
+    worst = max(norm_gap, key=norm_gap.get)
+    report(test="fixture16", case=name, dtype=dtype, elbo_rel=elbo_gap, gradnorm_rel_max=norm_gap[worst], worst=worst)
+    assert elbo_gap < ELBO_TOL[dtype]
+    assert rel_l2(model._last["mu"].cpu().numpy(), gold["mu"]) < 1.5 * FWD_TOL[dtype]
+    xh = xhat.double().cpu().numpy()
+    assert abs(xh.sum() / float(gold["output_sum"]) - 1) < FWD_TOL[dtype]
+    # B = 2 at the bottleneck gives BatchNorm few values per channel, hence the looser norm bound than GRAD_TOL
+    for n, gap in norm_gap.items():
+        assert gap < 4 * GRAD_TOL[dtype], (n, gap)
+
+
+FULL = [
+    # dtype, H, L, B, kld_weight         BASELINE.json configs[1] (bf16; f32 = the 1e-4 parity mode of the same workload),
+    ("f32", 128, 16, 256, 4.0),        # configs[2] (256x256, latent 64, batch 512, bf16 + f32 loss),
+    ("bf16", 128, 16, 256, 4.0),       # configs[4] (128x128, latent 128, 512 per GPU, f16 storage + f32 KL accumulate, beta 16)
+    ("bf16", 256, 64, 512, 1.0),
+    ("f16", 128, 128, 512, 16.0),
+]
+
+
+@pytest.mark.parametrize("cfg", FULL, ids=[f"{d}-{h}x{h}-L{l}-B{b}" for d, h, l, b, _ in FULL])
+def test_full_size_baseline_configs(cfg):
+    """Every single-GPU BASELINE.json configuration at FULL size on the HIP path (too large for the numpy oracle):
+    size-independent properties checked with independent torch reductions on the device.
+      * reconstruction term == BCE(xhat, x) from the returned xhat; KL term from the returned mu/log_var (f64);
+      * the backward is linear in the upstream gradient (loss*2 -> 2x gradients; exact for f32/bf16, rounding-level for
+        f16 whose stored gradients are rescaled), a second pass over the same batch reproduces the first bit for bit;
+      * the 16-bit ELBO against the f32 mode on the same batch (the 1e-4 mode, itself pinned to the reference at small
+        sizes): gap reported and bounded."""
+    import torch.nn.functional as F
+    dtype, H, L, B, kw = cfg
+    p = perturbed_params(L, H, 5, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 77)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 77, 5).reshape(B, L)).float().cuda()
+    tol = {"f32": 1e-5, "bf16": 2e-4, "f16": 2e-4}[dtype]
+    model = make_model(H, L, True, dtype, p, kld_weight=kw)
+    out3, xhat = model.fused_forward_backward(x, eps=eps)
+    g1 = model.flat_grads().detach().clone()
+    assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(out3).all())
+    mu, lv = model._last["mu"], model._last["lv"]
+    bce = F.binary_cross_entropy(xhat.double(), x.double()).item()
+    kld = (-0.5 * (1 + lv.double() - mu.double() ** 2 - lv.double().exp()).sum(1)).mean().item()
+    np.testing.assert_allclose(out3[1].item(), bce, rtol=tol)
+    np.testing.assert_allclose(-out3[2].item(), kld, rtol=tol)
+    np.testing.assert_allclose(out3[0].item(), bce + kw * kld, rtol=tol)
+    out3b, _ = model.fused_forward_backward(x, eps=eps)
+    assert torch.equal(model.flat_grads(), g1) and torch.equal(out3b, out3)
+    del model
+    m2 = make_model(H, L, True, dtype, p, kld_weight=kw)
+    m2.materialize_pre_latents = False
+    m2.set_next_eps(eps)
+    (2.0 * m2.loss(m2(x))["loss"]).backward()
+    if dtype == "f16":
+        assert rel_l2(m2.flat_grads().cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-4
+    else:
+        assert torch.equal(m2.flat_grads(), 2.0 * g1)
+    del m2
+    if dtype != "f32" and (H, L, B) != (256, 64, 512):   # (f32 at 256x256 / 512 takes the slow 64-bit-offset kernels: covered at B=2)
+        m3 = make_model(H, L, True, "f32", p, kld_weight=kw)
+        ref3, _ = m3.fused_forward_backward(x, eps=eps)
+        gap = float((out3 / ref3 - 1).abs().max())
+        gref = m3.flat_grads().double()
+        ggap = float((g1.double() - gref).norm() / gref.norm())
+        report(test="full_size", cfg=list(cfg), elbo_rel_vs_f32=gap, flat_grad_rel_l2_vs_f32=ggap)
+        assert gap < ELBO_TOL[dtype]
+        assert ggap < 2 * GRAD_TOL[dtype]
+
+
+def test_bce_edges_and_saturating_logits_on_hip():
+    """ATen's BCE conventions (log clamp -100, gradient clamp 1e-12; reference models.py:208) on the HIP kernels:
+    the reference-generated edge fixture through vae_elbo_generic, and saturating logits through the fused
+    output-conv + sigmoid + BCE kernels of all three storage modes against the oracle."""
+    from torch_vae_amd import _lib
+    gold = np.load(os.path.join(GOLD, "bce_edges.npz"))
+    n = gold["x"].size
+    xh = torch.from_numpy(gold["x"]).cuda(); tg = torch.from_numpy(gold["t"]).cuda()
+    mu = torch.zeros(1, 1, device="cuda"); lv = torch.zeros(1, 1, device="cuda")
+    out3 = torch.empty(3, device="cuda"); gx = torch.empty(n, device="cuda"); gm = torch.empty(1, 1, device="cuda"); gl = torch.empty(1, 1, device="cuda")
+    _lib.check(_lib.lib().vae_elbo_generic(xh.data_ptr(), tg.data_ptr(), mu.data_ptr(), lv.data_ptr(), n, 1, 1, 1.0, out3.data_ptr(),
+                                          gx.data_ptr(), gm.data_ptr(), gl.data_ptr(), torch.cuda.current_stream().cuda_stream), "elbo")
+    np.testing.assert_allclose(out3[1].item(), gold["per_elem"].astype(np.float64).mean(), rtol=1e-6)
+    np.testing.assert_allclose(gx.cpu().numpy() * n, gold["grad"], rtol=1e-6)     # (x - t) / max(x (1 - x), 1e-12)
+    assert out3[2].item() == 0.0
+    # saturating logits: an output bias of +-150 drives sigmoid to exactly 1 / 0 in f32, so every pixel hits a clamp
+    H, L, B = 32, 16, 4
+    x = vo.synth_pianoroll(B, H, 3)
+    eps = vo.counter_normal(B * L, 3, 5).reshape(B, L)
+    for bias in (150.0, -150.0, 30.0):
+        p = perturbed_params(L, H, 4, False)
+        p["final_layer.3.bias"] = np.array([bias])
+        c = vo.forward({k: v.astype(np.float32) for k, v in p.items()}, x.astype(np.float32), eps.astype(np.float32), None, train=True)
+        want = vo.loss(c)
+        want64 = vo.loss(vo.forward(p, x.astype(np.float64), eps, None, train=True))
+        for dtype in ("f32", "bf16", "f16"):
+            m = make_model(H, L, False, dtype, p)
+            out3, xhat = m.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+            assert bool(torch.isfinite(m.flat_grads()).all())
+            if abs(bias) > 100:
+                # f32 sigmoid saturates: the loss is count(mismatching pixels) * 100 / N exactly as ATen's clamp gives it
+                np.testing.assert_allclose(out3[1].item(), float(want["reconstruction_loss"]), rtol=1e-5)
+                assert float(xhat.max()) == float(xhat.min()) == (1.0 if bias > 0 else 0.0)
+            else:
+                np.testing.assert_allclose(out3[1].item(), float(want64["reconstruction_loss"]), rtol=ELBO_TOL[dtype])
+
+
+def test_wgrad_64bit_offset_fallback_agrees():
+    """The prefetching weight-gradient kernels index with 32-bit byte offsets; tensors of 4 GiB or more take the
+    synchronous kernel with 64-bit offsets.  Forced here (knob_wgrad_force_simple) at a small size: same operands and the
+    same MFMA products, only the split of K differs."""
+    from torch_vae_amd import _lib
+    H, L, B, gen = 64, 16, 6, True
+    p = perturbed_params(L, H, 5, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 9)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 9, 5).reshape(B, L)).float().cuda()
+    for dtype in ("bf16", "f16"):
+        grads = []
+        for force in (0, 1):
+            model = make_model(H, L, gen, dtype, p)
+            model._context(B)
+            assert _lib.lib().vae_set_option(model._ctx.handle, b"knob_wgrad_force_simple", force) == 0
+            model.fused_forward_backward(x, eps=eps)
+            grads.append(model.flat_grads().clone())
+        assert rel_l2(grads[1].cpu().numpy(), grads[0].cpu().numpy()) < 1e-5
+
+
+def test_backward_of_a_stale_forward_raises():
+    """The context keeps ONE forward's activations: backward of an older graph must fail loudly, not silently use the
+    newer batch (the reference's autograd would handle it; here it is an explicit error)."""
+    H, L, B = 32, 16, 4
+    m = make_model(H, L, False, "f32", perturbed_params(L, H, 2, False))
+    x1 = torch.from_numpy(vo.synth_pianoroll(B, H, 1)).cuda(); x2 = torch.from_numpy(vo.synth_pianoroll(B, H, 2)).cuda()
+    l1 = m.loss(m(x1))["loss"]
+    l2 = m.loss(m(x2))["loss"]
+    with pytest.raises(RuntimeError, match="no longer the model's last"):
+        l1.backward()
+    l2.backward()
+    assert bool(torch.isfinite(m.flat_grads()).all())
+
+
+def test_reference_checkpoint_loads_and_resumes(tmp_path):
+    """N2 pinned: a checkpoint WRITTEN BY THE REFERENCE's utils.safe_save_model (tests/golden/ckpt_R_b4_k1_f32.pt, made by
+    make_golden.py after the 3 steps of R_b4_k1) loads as train.py:320-329 does, and the next two steps reproduce the
+    losses the reference's own loop produced from that state; a checkpoint written by this package has the same keys
+    and tensor shapes, and round-trips."""
+    from argparse import Namespace
+    from torch_vae_amd.train import build_optimizer
+    from torch_vae_amd.utils import checkpoint_modules, load_checkpoint, safe_save_model
+    name = "R_b4_k1"
+    H, L, B, steps, total, kw, gen, seed = CASES[name]
+    nxt = np.load(os.path.join(GOLD, "ckpt_R_b4_k1_f32_next.npz"))
+    ck = torch.load(os.path.join(GOLD, "ckpt_R_b4_k1_f32.pt"), weights_only=False, map_location="cpu")
+    assert ck["epoch"] == 2 and ck["total_step"] == steps and ck["n_samples_seen"] == steps * B
+    # fc_mu / fc_var / decoder_input / final_layer are not in the reference's checkpoints (train.py:444-460) and are never
+    # optimised (train.py:210-225): they keep their initial values, which both sides regenerate from the counter generator
+    model = make_model(H, L, gen, "f32", vo.init_params(L, H, seed, gen), kld_weight=kw)
+    cfg = Namespace(batch_size_per_gpu=B, world_size=1, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW", scheduler="OneCycle",
+                    epochs=1, freeze_encoder=False)
+    opt, sched = build_optimizer(cfg, model, steps_per_epoch=total)
+    state = load_checkpoint(model, opt, sched, ck)
+    assert state["total_step"] == steps and state["n_samples_seen"] == steps * B
+    got = []
+    for s in range(steps, steps + 2):
+        x, eps = case_inputs(name, s)
+        out3, _ = model.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+        opt.step(); sched.step()
+        got.append(out3.tolist())
+    np.testing.assert_allclose(np.array(got), nxt["resumed_losses"], rtol=3e-4)
+    # the reverse direction: same keys, same tensor shapes, same optimizer / scheduler state layout
+    path = str(tmp_path / "run" / "checkpoint_latest.pt")
+    safe_save_model(checkpoint_modules(model, opt, sched), path, config=cfg, epoch=3, total_step=steps + 2, n_samples_seen=(steps + 2) * B)
+    mine = torch.load(path, weights_only=False, map_location="cpu")
+    assert set(mine) >= set(ck) - {"best_epoch"}
+    for mod in ("encoder", "decoder"):
+        assert list(mine[mod]) == list(ck[mod])
+        assert all(mine[mod][k].shape == ck[mod][k].shape and mine[mod][k].dtype == ck[mod][k].dtype for k in ck[mod])
+    assert set(mine["optimizer"]) == set(ck["optimizer"]) and len(mine["optimizer"]["state"]) == len(ck["optimizer"]["state"])
+    for i, st in ck["optimizer"]["state"].items():
+        assert set(mine["optimizer"]["state"][i]) == set(st)
+        assert all(mine["optimizer"]["state"][i][k].shape == st[k].shape for k in ("exp_avg", "exp_avg_sq"))
+    for gm, gr in zip(mine["optimizer"]["param_groups"], ck["optimizer"]["param_groups"]):
+        assert set(gm) >= set(gr) and gm["params"] == gr["params"]
+    assert set(mine["scheduler"]) == set(ck["scheduler"])
+    # all-modules flag (the reference loses fc_mu / fc_var / decoder_input / final_layer on resume)
+    full = checkpoint_modules(model, opt, sched, save_all_modules=True)
+    assert {"fc_mu", "fc_var", "decoder_input", "final_layer"} <= set(full)
+    # round trip into a fresh model continues identically
+    m2 = make_model(H, L, gen, "f32", vo.init_params(L, H, seed, gen), kld_weight=kw)
+    opt2, sched2 = build_optimizer(cfg, m2, steps_per_epoch=total)
+    load_checkpoint(m2, opt2, sched2, mine)
+    x, eps = case_inputs(name, steps + 2)
+    for mm, oo in ((model, opt), (m2, opt2)):
+        mm.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
+        oo.step()
+    assert rel_l2(m2.flat_parameters().cpu().numpy(), model.flat_parameters().cpu().numpy()) < 1e-6
+
+
+def test_evaluate_matches_reference_values():
+    """N3 pinned: count / cross-entropy / mse / mae the REFERENCE's evaluation.evaluate produced (tests/golden/evaluate_R.npz)
+    on a two-batch loader whose dataset is one sample short of the batches (the padding trim, evaluation.py:88-95)."""
+    from torch_vae_amd.evaluation import evaluate
+    gold = np.load(os.path.join(GOLD, "evaluate_R.npz"))
+    H, L, B, seed, n_samples = 32, 16, 4, 21, 7
+    m = make_model(H, L, False, "f32", vo.init_params(L, H, seed, False))
+
+    class Loader(list):
+        pass
+
+    loader = Loader((torch.from_numpy(vo.synth_pianoroll(B, H, seed * 1000 + i)), torch.zeros(B, dtype=torch.long)) for i in range(2))
+    loader.dataset = range(n_samples)
+    epss = [torch.from_numpy(vo.counter_normal(B * L, seed * 1000 + i, 5).reshape(B, L)).float().cuda() for i in range(2)]
+    fwd = m.forward
+
+    def forward_with_eps(x):
+        m.set_next_eps(epss.pop(0)[: x.shape[0]])
+        return fwd(x)
+
+    m.forward = forward_with_eps
+    res = evaluate(loader, m, "cuda", verbosity=0)
+    assert res["count"] == int(gold["count"]) == n_samples
+    assert res["cross-entropy"] == float(gold["cross-entropy"]) == 0.0
+    np.testing.assert_allclose(res["mse"], float(gold["mse"]), rtol=1e-4)
+    np.testing.assert_allclose(res["mae"], float(gold["mae"]), rtol=1e-4)
+
+
+def test_data_parallel_product_path_two_ranks():
+    """train.fused_step / build_optimizer with world_size 2 (two ranks sharing this GPU over gloo) against the oracle's
+    R-replica simulation: initial broadcast from deliberately different replicas, identical parameters on both ranks
+    after every step, mean gradients in .grad, per-rank reparameterisation noise, lr scaling (tests/dp_product_worker.py)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "dp_product_worker.py"), ROOT]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("DP_PRODUCT_OK") == 2
+
+
+def test_library_allreduce_single_rank_rccl():
+    """vae_comm_init / vae_allreduce_grads / vae_broadcast_state on a real RCCL communicator (one rank: the only size a
+    one-GPU box can form): the overlapped and the in-line exchange both leave the step unchanged bit for bit, and
+    train.fused_step routes through the library when asked to."""
+    import ctypes as C
+    import torch.distributed as dist
+    from torch_vae_amd import _lib
+    from torch_vae_amd.optim import FusedAdamW
+    from torch_vae_amd.train import enable_library_allreduce, fused_step
+    H, L, B, gen = 64, 16, 6, True
+    p = perturbed_params(L, H, 33, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 9)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 9, 5).reshape(B, L)).float().cuda()
+
+    def one_step(mode):
+        m = make_model(H, L, gen, "f32", p)
+        opt = FusedAdamW([{"params": list(m.encoder.parameters())}, {"params": list(m.decoder.parameters())}], lr=1e-3)
+        if mode is not None:
+            assert enable_library_allreduce(m)
+        out3, _ = fused_step(m, opt, x, eps=eps, overlap=mode)
+        if mode is not None:
+            assert m.library_comm_world() == 1
+            st = torch.cuda.current_stream().cuda_stream
+            before = m.flat_parameters().detach().clone()
+            _lib.check(_lib.lib().vae_broadcast_state(m._ctx.handle, m.flat_parameters().data_ptr(), m._bnflat.data_ptr(), m._nbt.data_ptr(), 0, st), "bcast")
+            assert torch.equal(before, m.flat_parameters())
+        return out3.cpu().numpy(), m.flat_parameters().detach().cpu().numpy().copy(), m.flat_grads().detach().cpu().numpy().copy()
+
+    ref = one_step(None)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29573")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for mode in (False, True):
+            got = one_step(mode)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
+    # the entry points refuse to run without a communicator, loudly
+    m = make_model(H, L, gen, "f32", p)
+    m._context(B)
+    offs = (C.c_int64 * 1)(0); sizes = (C.c_int64 * 1)(16)
+    assert _lib.lib().vae_allreduce_grads(m._ctx.handle, m.flat_grads().data_ptr(), 1, offs, sizes, 1, torch.cuda.current_stream().cuda_stream) != 0
+    assert b"no communicator" in _lib.lib().vae_last_error()

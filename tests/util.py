@@ -3,6 +3,24 @@ import numpy as np
 
 from oracle import vae_oracle as vo
 
+CASES = {
+    # name: H, L, B, steps, total_steps, kld_weight, generalised, seed   (the table tests/golden/make_golden.py generates)
+    "R_b4_k1": (32, 16, 4, 3, 10, 1.0, False, 1),
+    "R_b32_k1": (32, 16, 32, 20, 200, 1.0, False, 2),
+    "R_b32_k4": (32, 16, 32, 2, 10, 4.0, False, 3),
+    "R_b32_k16": (32, 16, 32, 2, 10, 16.0, False, 4),
+    "R_b256_k1": (32, 16, 256, 2, 10, 1.0, False, 5),
+    "G_h64_l16_b4": (64, 16, 4, 2, 10, 1.0, True, 6),
+    "G_h64_l64_b8": (64, 64, 8, 2, 10, 1.0, True, 7),
+    "G_h128_l16_b2": (128, 16, 2, 1, 10, 1.0, True, 8),
+    "G_h128_l128_b2": (128, 128, 2, 1, 10, 4.0, True, 9),
+    # BASELINE.json configs[2] / configs[4] shapes and the reference's default latent size (round 2)
+    "G_h256_l64_b2": (256, 64, 2, 1, 10, 1.0, True, 10),
+    "G_h128_l128_b2_k1": (128, 128, 2, 1, 10, 1.0, True, 11),
+    "G_h128_l128_b2_k16": (128, 128, 2, 1, 10, 16.0, True, 12),
+    "R_l10_b8": (32, 10, 8, 2, 10, 1.0, False, 13),
+}
+
 # conv biases that feed a train-mode BatchNorm: analytically zero gradient
 PRE_BN_BIAS = tuple([f"encoder.{i}.0.bias" for i in range(4)] + [f"decoder.{i}.0.bias" for i in range(3)]
                     + ["final_layer.0.bias"])

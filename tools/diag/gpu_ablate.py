@@ -1,6 +1,6 @@
 """Ablation / knob timing helper for the GPU box (not a pytest file): per-kernel HIP-event times under option settings."""
 import sys, os, time, json, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd import _lib

@@ -1,5 +1,5 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import vae_oracle as vo
 from tests.util import perturbed_params, make_model
 from tests.gpu_debug_layers import dbg

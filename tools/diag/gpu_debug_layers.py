@@ -3,7 +3,7 @@ oracle and prints relative errors.  Not a pytest file; run as a script."""
 import sys, os, json
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import vae_oracle as vo
 from torch_vae_amd import _lib
 from torch_vae_amd.models import VanillaVAE

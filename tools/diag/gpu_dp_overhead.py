@@ -1,6 +1,6 @@
 """Diagnostic: process group created BEFORE the model/context (as bench.py does)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
 from argparse import Namespace

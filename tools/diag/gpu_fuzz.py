@@ -3,7 +3,7 @@
 import sys, os, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import vae_oracle as vo
 from util import PRE_BN_BIAS, flat_grad_dict, make_model, perturbed_params, rel_l2

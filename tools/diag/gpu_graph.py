@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): capture forward+ELBO+backward into a HIP graph (torch.cuda.CUDAGraph) and compare replay with eager."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd.models import VanillaVAE

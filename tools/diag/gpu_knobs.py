@@ -1,6 +1,6 @@
 """Knob sweep on the GPU box (not a pytest file): times the step with different persistent-grid sizes."""
 import sys, os, time, itertools, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd import _lib

@@ -2,7 +2,7 @@
 (same results expected: a wave owns whole taps, the K order does not change), then step time with either."""
 import json, os, subprocess, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import vae_oracle as vo
 from torch_vae_amd import _lib

@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): a few hundred bf16 training steps at the benchmark size - the ELBO must fall, stay finite and two
 identical runs must agree bit for bit (races between the caller's stream and the side streams would break that)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd.models import VanillaVAE

@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): per-phase cycle shares of the pipelined down kernel for chosen layers."""
 import sys, os, json, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch_vae_amd import _lib
 from torch_vae_amd.models import VanillaVAE

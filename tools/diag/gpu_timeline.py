@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): start/end of every profiled launch of one training step (both streams)."""
 import sys, os, json, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd import _lib

@@ -15,6 +15,8 @@ NUM_PARAMS = 40
 NUM_BN = 8
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
+DTYPE_F16 = 2
+COMM_ID_BYTES = 128
 
 PARAM_NAMES = (
     [f"encoder.{i}.{j}" for i in range(4) for j in ("0.weight", "0.bias", "1.weight", "1.bias")]
@@ -66,6 +68,12 @@ def lib():
     _sig(L.vae_backward, i32, [p, p, p, p, p, p, p, p, p, p, f32, i32, p])
     _sig(L.vae_backward_part, i32, [p, p, p, p, p, p, p, p, p, p, f32, i32, i32, p])
     _sig(L.vae_comm_stream, i32, [p, p, C.POINTER(C.c_void_p)])
+    _sig(L.vae_comm_unique_id, i32, [p])
+    _sig(L.vae_comm_init, i32, [p, i32, i32, p])
+    _sig(L.vae_comm_world, i32, [p])
+    _sig(L.vae_comm_destroy, i32, [p])
+    _sig(L.vae_allreduce_grads, i32, [p, p, i32, i64p, i64p, i32, p])
+    _sig(L.vae_broadcast_state, i32, [p, p, p, p, i32, p])
     _sig(L.vae_adamw_step, i32, [p, p, p, p, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32, i32, p])
     _sig(L.vae_train_step, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32,
                                  i32, p, p, p, p, p, p])
@@ -85,7 +93,8 @@ def lib():
 EXPORTS = [
     "vae_last_error", "vae_abi_version", "vae_param_layout", "vae_bn_layout", "vae_create", "vae_destroy",
     "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_loss_deferred", "vae_elbo_generic",
-    "vae_backward", "vae_backward_part", "vae_comm_stream", "vae_adamw_step", "vae_train_step", "vae_synth_pianoroll", "vae_profile",
+    "vae_backward", "vae_backward_part", "vae_comm_stream", "vae_comm_unique_id", "vae_comm_init", "vae_comm_world",
+    "vae_comm_destroy", "vae_allreduce_grads", "vae_broadcast_state", "vae_adamw_step", "vae_train_step", "vae_synth_pianoroll", "vae_profile",
     "vae_profile_report", "vae_profile_sequence", "vae_profile_timeline", "vae_debug_stamps", "vae_debug_tensor",
     "vae_selftest_tr16", "vae_set_option",
 ]

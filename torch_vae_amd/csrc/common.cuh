@@ -11,15 +11,27 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+static constexpr int WG_KP = 64;  // weight-gradient kernels: low-res pixels per K tile
 
 #define LDS_PTR(T) T __attribute__((address_space(3)))*
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ float tofloat(float v) { return v; }
 __device__ __forceinline__ float tofloat(bf16 v) { return (float)v; }
+__device__ __forceinline__ float tofloat(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T fromfloat(float v);
 template <> __device__ __forceinline__ float fromfloat<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 fromfloat<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 fromfloat<f16>(float v) { return (f16)v; }
+
+// the two 16-bit storage types share every code path; H16<T> names their vector types
+template <typename T> struct H16;
+template <> struct H16<bf16> { typedef bf16x8 v8; typedef bf16x2 v2; };
+template <> struct H16<f16> { typedef f16x8 v8; typedef f16x2 v2; };
 
 // Round a value the way it will be stored (so statistics see the stored tensor).
 template <typename T> __device__ __forceinline__ float round_as(float v) { return tofloat(fromfloat<T>(v)); }
@@ -37,6 +49,12 @@ template <> struct Vec16<bf16> {
     bf16x8 v;
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+template <> struct Vec16<f16> {
+    static constexpr int N = 8;
+    f16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
 };
 template <typename T> __device__ __forceinline__ Vec16<T> zero_vec16() {
     Vec16<T> r;
@@ -70,12 +88,21 @@ template <> struct Frag<bf16> {
     __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16)x; }
 };
 
+template <> struct Frag<f16> {
+    f16x8 v;
+    __device__ __forceinline__ void set(int j, float x) { v[j] = (f16)x; }
+};
+
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<f16>& a, const Frag<f16>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
 }
 
 // 8 consecutive elements from a generic (global or LDS) pointer, 16-B aligned.
@@ -90,6 +117,12 @@ __device__ __forceinline__ Frag<float> load_frag(const float* p) {
 __device__ __forceinline__ Frag<bf16> load_frag(const bf16* p) {
     Frag<bf16> f;
     f.v = *reinterpret_cast<const bf16x8*>(p);
+    return f;
+}
+
+__device__ __forceinline__ Frag<f16> load_frag(const f16* p) {
+    Frag<f16> f;
+    f.v = *reinterpret_cast<const f16x8*>(p);
     return f;
 }
 
@@ -146,6 +179,7 @@ struct BnFuse {
     float* running_mean; float* running_var; long long* nbt;
     float* dgamma; float* dbeta; float* dconv_bias;
     double count; float eps, momentum;
+    float ginv;                     // backward: dgamma / dbeta are written times ginv (f16 gradient scaling, vae_ctx::ginv)
     int C, mode, update_running;    // mode 0: coefficients are read from the block; 1: forward; 2: backward
 };
 enum { BNF_NONE = 0, BNF_FWD = 1, BNF_BWD = 2 };
@@ -177,13 +211,13 @@ __device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool wr
         k0 = (float)s; k1 = (float)(-s * m2 * invstd); k2 = (float)(-s * m1 + s * m2 * mean * invstd);
         if (writer) {
             f.block[LC_P0 * C + c] = k0; f.block[LC_P1 * C + c] = k1; f.block[LC_P2 * C + c] = k2;
-            f.dgamma[c] = (float)sdzx; f.dbeta[c] = (float)sdz;
+            f.dgamma[c] = (float)(sdzx * (double)f.ginv); f.dbeta[c] = (float)(sdz * (double)f.ginv);
             if (f.dconv_bias) f.dconv_bias[c] = 0.f;
         }
     }
 }
 // standalone finalisation (consumers without the fused prologue, e.g. the one-tile-per-workgroup kernels)
-__global__ void bn_finalize_kernel(BnFuse f) {
+static __global__ void bn_finalize_kernel(BnFuse f) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= f.C) return;
     float k0, k1, k2;

@@ -351,16 +351,16 @@ template <typename T> struct WgradArgs {
     BnFuse fuse;                                                 // mode == BNF_BWD: the gradient operand's coefficients come from batch statistics
 };
 
-static constexpr int WG_KP = 64;  // low-res pixels per K tile
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
-// k-major bf16 fragment from two transposed LDS reads (rows k..k+3 and k+4..k+7 of a [k][channel] image)
-__device__ __forceinline__ Frag<bf16> frag_tr16(const char* ad0, const char* ad1) {
+// k-major 16-bit fragment from two transposed LDS reads (rows k..k+3 and k+4..k+7 of a [k][channel] image)
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_tr16(const char* ad0, const char* ad1) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad0);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))ad1);
     const s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    Frag<bf16> f;
-    f.v = __builtin_bit_cast(bf16x8, w);
+    Frag<T> f;
+    f.v = __builtin_bit_cast(typename H16<T>::v8, w);
     return f;
 }
 
@@ -585,14 +585,14 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
                 if (a.use_tr16) {
                     const int k0 = ks * 16 + 8 * (g4 >> 1) + q, k1 = k0 + 4;
                     const int col = (wa * 32 + 16 * (g4 & 1) + 4 * p) * 2;
-                    af = frag_tr16(stile + k0 * SPITCH + col, stile + k1 * SPITCH + col);
+                    af = frag_tr16<T>(stile + k0 * SPITCH + col, stile + k1 * SPITCH + col);
                     growbase[0] = ((k0 >> (a.lth + a.ltw)) * PH + 2 * ((k0 >> a.ltw) & (th - 1))) * PW + 2 * (k0 & (tw - 1));
                     growbase[1] = ((k1 >> (a.lth + a.ltw)) * PH + 2 * ((k1 >> a.ltw) & (th - 1))) * PW + 2 * (k1 & (tw - 1));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int k = ks * 16 + 8 * h + j;
-                        af.v[j] = *reinterpret_cast<const bf16*>(stile + k * SPITCH + (wa * 32 + r) * 2);
+                        af.v[j] = *reinterpret_cast<const T*>(stile + k * SPITCH + (wa * 32 + r) * 2);
                         growbase[j] = ((k >> (a.lth + a.ltw)) * PH + 2 * ((k >> a.ltw) & (th - 1))) * PW + 2 * (k & (tw - 1));
                     }
                 }
@@ -611,11 +611,11 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
                     } else {
                         if (a.use_tr16) {
                             const int col = (wb * 32 + 16 * (g4 & 1) + 4 * p) * 2;
-                            bf = frag_tr16(gtile + (growbase[0] + toff) * GPITCH + col, gtile + (growbase[1] + toff) * GPITCH + col);
+                            bf = frag_tr16<T>(gtile + (growbase[0] + toff) * GPITCH + col, gtile + (growbase[1] + toff) * GPITCH + col);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                bf.v[j] = *reinterpret_cast<const bf16*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 2);
+                                bf.v[j] = *reinterpret_cast<const T*>(gtile + (growbase[j] + toff) * GPITCH + (wb * 32 + r) * 2);
                         }
                     }
                     mma(acc[ti], af, bf);
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
 // out[(a*CB+b)*9+t] = sum_s slab[s][t][a][b]   (CA>0: conv weight layout [A][B][3][3])
 // out[j]            = sum_s slab[s][j]          (CA==0)
 // block = 64 outputs x 4 slab groups; each thread keeps 8 independent loads in flight.
-__global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n,
-                                                          float* __restrict__ out, int CA, int CB) {
+static __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n,
+                                                                 float* __restrict__ out, int CA, int CB, float scale) {
     __shared__ float part[4][64];
     const int jl = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + jl;
     float s = 0.f;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
     part[g][jl] = s;
     __syncthreads();
     if (g == 0 && j < n) {
-        s = part[0][jl] + part[1][jl] + part[2][jl] + part[3][jl];
+        s = (part[0][jl] + part[1][jl] + part[2][jl] + part[3][jl]) * scale;
         if (CA > 0) {
             const int t = j / (CA * CB), rem = j - t * CA * CB;
             out[(size_t)rem * 9 + t] = s;
@@ -677,15 +677,17 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
 //   part[p][t] = sum_c a[p][c] w[t][c]   : M = patch pixels (tile + 1-pixel halo), K = 32 channels, N = 9 taps
 //   logit[q]   = bias + sum_t part[q + off(t)][t]
 // Persistent workgroups over 8x32-pixel tiles; next tile's (8+2)x(32+2) patch of y is prefetched.
-struct ConvOutFwdMfmaArgs {
-    const bf16* yf; const float* coef; const float* wt; const float* bias; const float* target;
+template <typename T> struct ConvOutFwdMfmaArgs {
+    const T* yf; const float* coef; const float* wt; const float* bias; const float* target;
     float* xhat; float* dlogit; double* accum;
     int B, H, W, n_tiles; float inv_n, slope;
     BnFuse fuse;
     int rev;
 };
 
-__global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfmaArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfmaArgs<T> a) {
+    typedef typename H16<T>::v8 T8;
     constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, NP = PH * PW, NPAD = 384, PITCH = 80, NCHK = NP * 4, MAXI = 6;
     __shared__ __attribute__((aligned(16))) char atile[NPAD * PITCH];
     __shared__ float part[NPAD * 9];
@@ -700,11 +702,11 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
     // rows NP..NPAD of the patch image stay zero
     for (int i = tid; i < (NPAD - NP) * PITCH / 16; i += 256) *reinterpret_cast<f32x4*>(atile + NP * PITCH + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     // B operand: B[k = channel][col = tap r]
-    Frag<bf16> wf[2];
+    Frag<T> wf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf[ks].v[j] = (bf16)(r < 9 ? a.wt[r * 32 + ks * 16 + 8 * h + j] : 0.f);
+        for (int j = 0; j < 8; ++j) wf[ks].v[j] = (T)(r < 9 ? a.wt[r * 32 + ks * 16 + 8 * h + j] : 0.f);
     const float bo = a.bias[0];
     float bsum = 0.f;
 
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
         b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
     };
-    bf16x8 pre[MAXI]; int ok[MAXI]; float pretg;
+    T8 pre[MAXI]; int ok[MAXI]; float pretg;
     // chunk id = tid + 256u: patch pixel id>>2, channel quarter id&3 = tid&3 - the same quarter for every chunk of a thread
     auto prefetch = [&](int tile) {
         int b, y0, x0; tile_origin(tile, b, y0, x0);
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
             const int py = pix / PW, px = pix - py * PW, gy = y0 - 1 + py, gx = x0 - 1 + px;
             ok[u] = id < NCHK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             const uint32_t g = ok[u] ? (uint32_t)(base + (py * a.W + px) * 32) * 2u : 0u;   // byte offset (< 4 GiB: host check)
-            pre[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.yf) + g);
+            pre[u] = *reinterpret_cast<const T8*>(reinterpret_cast<const char*>(a.yf) + g);
         }
     };
     __syncthreads();                     // cf published
@@ -744,16 +746,16 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int id = tid + 256 * u;
-            bf16x8 o;
+            T8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f32x2 z = f32x2{(float)pre[u][2 * e], (float)pre[u][2 * e + 1]} * kc[e] + kh[e];
                 const f32x2 zs = z * a.slope;
                 z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
-                o[2 * e] = (bf16)z.x; o[2 * e + 1] = (bf16)z.y;
+                o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
             }
-            if (!ok[u]) o = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (id < NCHK) *reinterpret_cast<bf16x8*>(atile + (id >> 2) * PITCH + (id & 3) * 16) = o;
+            if (!ok[u]) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (id < NCHK) *reinterpret_cast<T8*>(atile + (id >> 2) * PITCH + (id & 3) * 16) = o;
         }
         __syncthreads();
         const float tg = pretg;
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                Frag<bf16> af = load_frag(reinterpret_cast<const bf16*>(atile + (row0 + r) * PITCH + ks * 32) + h * 8);
+                Frag<T> af = load_frag(reinterpret_cast<const T*>(atile + (row0 + r) * PITCH + ks * 32) + h * 8);
                 mma(acc, af, wf[ks]);
             }
             if (r < 9) {
@@ -804,14 +806,16 @@ __global__ __launch_bounds__(256, 2) void convout_fwd_mfma_kernel(ConvOutFwdMfma
 //   dz = dA * leaky'(z), per-channel sum dz, sum dz*xhat, sum dl
 // Persistent workgroups walk 8x32-pixel tiles; the next tile's y is prefetched into registers while the
 // current one is in the matrix pipe; dz goes out through LDS as whole 64-byte pixels.
-struct ConvOutBwdMfmaArgs {
-    const bf16* yf; const float* ocoef; const float* wt; const float* dlogit; const float* gscale;
-    bf16* dz; float* slab; double* stat; double* dbias;
+template <typename T> struct ConvOutBwdMfmaArgs {
+    const T* yf; const float* ocoef; const float* wt; const float* dlogit; const float* gscale;
+    T* dz; float* slab; double* stat; double* dbias;
     int B, H, W, n_tiles; float slope;
-    int rev;
+    int rev; float gmul;
 };
 
-__global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfmaArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfmaArgs<T> a) {
+    typedef typename H16<T>::v8 T8;
     constexpr int TH = 8, TW = 32, PITCH = 80, DW = TW + 2, DH = TH + 2;
     __shared__ __attribute__((aligned(16))) char ytile[TH * TW * PITCH];
     __shared__ float dl_s[DH * DW + 6];
@@ -819,14 +823,14 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const float gs = (a.gscale ? a.gscale[0] : 1.f) * a.gmul;
     const float sc = a.ocoef[LC_SC * 32 + r], sh = a.ocoef[LC_SH * 32 + r];
     const float is = a.ocoef[LC_INVSTD * 32 + r], xm = a.ocoef[LC_XM * 32 + r];
 
     // weights as the B operand of dA: B[k = tap][col = channel r]
-    Frag<bf16> wfrag;
+    Frag<T> wfrag;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int t = 8 * h + j; wfrag.v[j] = (bf16)(t < 9 ? a.wt[t * 32 + r] : 0.f); }
+    for (int j = 0; j < 8; ++j) { const int t = 8 * h + j; wfrag.v[j] = (T)(t < 9 ? a.wt[t * 32 + r] : 0.f); }
 
     f32x16 accw;
 #pragma unroll
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
         b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
     };
     // each thread owns 4 of the tile's 1024 16-byte chunks: chunk id = tid + 256*u -> pixel id>>2, quarter id&3
-    bf16x8 pre[4];
+    T8 pre[4];
     float predl[2];     // and up to 2 of the (TH+2)x(TW+2) dlogit values
     auto prefetch = [&](int tile) {
         int b, y0, x0; tile_origin(tile, b, y0, x0);
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
         for (int u = 0; u < 4; ++u) {
             const int id = tid + 256 * u, pix = id >> 2, qq = id & 3;
             const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
-            pre[u] = *reinterpret_cast<const bf16x8*>(a.yf + g);
+            pre[u] = *reinterpret_cast<const T8*>(a.yf + g);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = tid + 256 * u;
-            *reinterpret_cast<bf16x8*>(ytile + (id >> 2) * PITCH + (id & 3) * 16) = pre[u];
+            *reinterpret_cast<T8*>(ytile + (id >> 2) * PITCH + (id & 3) * 16) = pre[u];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -886,12 +890,12 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
 #pragma unroll
             for (int i = 0; i < 16; ++i) acca[mb][i] = 0.f;
             const int ly = 2 * wave + mb, lx = r;
-            Frag<bf16> af;
+            Frag<T> af;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int t = 8 * h + j, tt = t < 9 ? t : 0;
                 const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
-                af.v[j] = (bf16)(t < 9 ? v : 0.f);
+                af.v[j] = (T)(t < 9 ? v : 0.f);
             }
             mma(acca[mb], af, wfrag);
         }
@@ -900,16 +904,16 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
         for (int ks = 0; ks < 4; ++ks) {
             const int k0 = wave * 64 + ks * 16 + 8 * (g4 >> 1) + q, k1 = k0 + 4;
             const int col = (16 * (g4 & 1) + 4 * p) * 2;
-            Frag<bf16> yfrag = frag_tr16(ytile + k0 * PITCH + col, ytile + k1 * PITCH + col);
-            Frag<bf16> afr, bfr;
+            Frag<T> yfrag = frag_tr16<T>(ytile + k0 * PITCH + col, ytile + k1 * PITCH + col);
+            Frag<T> afr, bfr;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) afr.v[j] = (bf16)leaky((float)yfrag.v[j] * sc + sh, a.slope);
+            for (int j = 0; j < 8; ++j) afr.v[j] = (T)leaky((float)yfrag.v[j] * sc + sh, a.slope);
             const int tt = r < 9 ? r : 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int pix = wave * 64 + ks * 16 + 8 * h + j, ly = pix >> 5, lx = pix & 31;
                 const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
-                bfr.v[j] = (bf16)(r < 9 ? v : 0.f);
+                bfr.v[j] = (T)(r < 9 ? v : 0.f);
             }
             mma(accw, afr, bfr);
         }
@@ -919,10 +923,10 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pix = (2 * wave + mb) * 32 + acc_row(i, lane);
-                bf16* cell = reinterpret_cast<bf16*>(ytile + pix * PITCH) + r;
+                T* cell = reinterpret_cast<T*>(ytile + pix * PITCH) + r;
                 const float yv = (float)(*cell), z = yv * sc + sh;
-                const float dzv = (float)(bf16)(z > 0.f ? acca[mb][i] : acca[mb][i] * a.slope);
-                *cell = (bf16)dzv;
+                const float dzv = (float)(T)(z > 0.f ? acca[mb][i] : acca[mb][i] * a.slope);
+                *cell = (T)dzv;
                 s1 += dzv; s2 += dzv * (yv * is + xm);
             }
         }
@@ -931,9 +935,9 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(ytile + pix * PITCH + qq * 16);
+            const T8 v = *reinterpret_cast<const T8*>(ytile + pix * PITCH + qq * 16);
             const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
-            *reinterpret_cast<bf16x8*>(a.dz + g) = v;
+            *reinterpret_cast<T8*>(a.dz + g) = v;
         }
     }
 
@@ -1003,7 +1007,9 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs<T> a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            Frag<T> bf = load_frag(a.Bp + ((size_t)(k >> 3) * a.Npad + n0 + nt * 32 + r) * 8);
+            // columns beyond Npad (only if a launcher ever picks an NT that does not divide Npad/32) read column 0 and are dropped below
+            const int n = n0 + nt * 32 + r;
+            Frag<T> bf = load_frag(a.Bp + ((size_t)(k >> 3) * a.Npad + (n < a.Npad ? n : 0)) * 8);
             mma(acc[nt], af, bf);
         }
     }
@@ -1011,7 +1017,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs<T> a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int mm = blockIdx.x * 128 + wave * 32 + acc_row(i, lane);
-            if (mm < a.M) a.slab[((size_t)blockIdx.y * a.M + mm) * a.Npad + n0 + nt * 32 + r] = acc[nt][i];
+            const int mm = blockIdx.x * 128 + wave * 32 + acc_row(i, lane), n = n0 + nt * 32 + r;
+            if (mm < a.M && n < a.Npad) a.slab[((size_t)blockIdx.y * a.M + mm) * a.Npad + n] = acc[nt][i];
         }
 }

@@ -61,6 +61,11 @@ __device__ __forceinline__ void epi_pair(float a0, float a1, T* c0, T* c1, bool 
     }
 }
 
+template <> __device__ __forceinline__ f32x2 round_pair<f16>(f32x2 v, f16& o0, f16& o1) {
+    const f16x2 b = __builtin_convertvector(v, f16x2);
+    o0 = b.x; o1 = b.y;
+    return __builtin_convertvector(b, f32x2);
+}
 template <typename T>
 __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int ntiles_n, int nch_out) {
     int mt = pi / ntiles_n; const int nt = pi - mt * ntiles_n;

@@ -23,6 +23,11 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float* o)
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
 }
+template <> __device__ __forceinline__ void load8<f16>(const f16* p, float* o) {
+    f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+}
 template <typename T> __device__ __forceinline__ void store8(T* p, const float* o);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float* o) {
     f32x4 a, b;
@@ -35,6 +40,13 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float* o
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = (bf16)o[i];
     *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+template <> __device__ __forceinline__ void store8<f16>(f16* p, const float* o) {
+    f16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f16)o[i];
+    *reinterpret_cast<f16x8*>(p) = a;
 }
 
 // ---------------------------------------------------------------------------
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void convout_fwd_kernel(ConvOutArgs a) {
 
 // dlogit = g_xhat * xhat*(1-xhat) [+ gscale * dlogit_std]: caller-supplied dL/dxhat, optionally on top
 // of the fused standard-ELBO gradient
-__global__ void dlogit_combine_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+static __global__ void dlogit_combine_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
                                       const float* __restrict__ dstd, const float* __restrict__ gscale,
                                       float* __restrict__ dlogit, long n) {
     const float gs = gscale ? gscale[0] : 1.f;
@@ -253,7 +265,7 @@ __global__ void dlogit_combine_kernel(const float* __restrict__ g, const float* 
 }
 
 // generic F.binary_cross_entropy(mean) forward + grad w.r.t. the prediction
-__global__ void bce_kernel(const float* __restrict__ xh_, const float* __restrict__ tg_, float* __restrict__ gx,
+static __global__ void bce_kernel(const float* __restrict__ xh_, const float* __restrict__ tg_, float* __restrict__ gx,
                            double* __restrict__ accum, long n, float inv_n) {
     __shared__ float wred[4];
     float bsum = 0.f;
@@ -278,6 +290,7 @@ struct ConvOutBwdArgs {
     double* stat;                         // [2][32]
     double* dbias;                        // sum of dlogit
     int B, H, W; float slope;
+    float gmul;                           // gradient scale entering the backward (f16 storage; 1 otherwise)
 };
 
 template <typename T>
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
     const int P = a.B * a.H * a.W, lw = 31 - __builtin_clz(a.W), lh = 31 - __builtin_clz(a.H);
     const T* yf = reinterpret_cast<const T*>(a.yf);
     T* dzp = reinterpret_cast<T*>(a.dz);
-    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const float gs = (a.gscale ? a.gscale[0] : 1.f) * a.gmul;
     float sc[8], sh[8], is[8], xm[8], wr[8][9], dw[8][9], s1[8], s2[8], sdl = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(256) void convout_bwd_kernel(ConvOutBwdArgs a) {
 // ---------------------------------------------------------------------------
 // BatchNorm: train-mode finalisation lives in common.cuh (BnFuse, folded into the consumer kernels).
 // eval-mode coefficients from running statistics (evaluation path / model.eval())
-__global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+static __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float* block, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -370,7 +383,7 @@ struct LatentFwdArgs {
     int B, L;
 };
 constexpr int LAT_LANES = 32;   // lanes per (b,l): the split-K slabs are summed in parallel, all loads of a lane in flight
-__global__ void latent_fwd_kernel(LatentFwdArgs a) {
+static __global__ void latent_fwd_kernel(LatentFwdArgs a) {
     __shared__ float wred[4];
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LAT_LANES, sub = threadIdx.x & (LAT_LANES - 1);
     float term = 0.f;
@@ -399,7 +412,7 @@ __global__ void latent_fwd_kernel(LatentFwdArgs a) {
 
 // ELBO scalars (models.py:216-225): loss = bce + kld_weight*kld ; kld_loss reported with flipped sign.
 // nrep: replicas of the accumulator block (STAT_R for a context's accumulators, 1 for the generic-loss buffer)
-__global__ void loss_finalize_kernel(const double* accum, float* out3, double inv_n, double inv_b, float kld_weight, int nrep) {
+static __global__ void loss_finalize_kernel(const double* accum, float* out3, double inv_n, double inv_b, float kld_weight, int nrep) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double a0 = 0.0, a1 = 0.0;
         for (int rep = 0; rep < nrep; ++rep) { a0 += accum[rep * 8 + 0]; a1 += accum[rep * 8 + 1]; }
@@ -407,7 +420,7 @@ __global__ void loss_finalize_kernel(const double* accum, float* out3, double in
         out3[0] = (float)(bce + (double)kld_weight * kld); out3[1] = (float)bce; out3[2] = (float)(-kld);
     }
 }
-__global__ void kld_only_kernel(const float* mu, const float* lv, double* accum, int n, float k, float* gmu, float* glv) {
+static __global__ void kld_only_kernel(const float* mu, const float* lv, double* accum, int n, float k, float* gmu, float* glv) {
     __shared__ float wred[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float term = 0.f;
@@ -429,8 +442,9 @@ struct LatentBwdArgs {
     const float* gmu; const float* glv; const float* gz;   // optional external grads [B,L]
     float* dlat;                          // [B][2L]: dmu | dlv
     int B, L; float kld_weight; int add_kl;
+    float gmul;                           // every upstream gradient entering here is multiplied by it (f16 gradient scaling; 1 otherwise)
 };
-__global__ void latent_bwd_kernel(LatentBwdArgs a) {   // LAT_LANES lanes per (b,l)
+static __global__ void latent_bwd_kernel(LatentBwdArgs a) {   // LAT_LANES lanes per (b,l)
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LAT_LANES, sub = threadIdx.x & (LAT_LANES - 1);
     const bool ok = i < a.B * a.L;
     const int b = ok ? i / a.L : 0, l = ok ? i % a.L : 0;
@@ -444,24 +458,24 @@ __global__ void latent_bwd_kernel(LatentBwdArgs a) {   // LAT_LANES lanes per (b
 #pragma unroll
     for (int o = 1; o < LAT_LANES; o <<= 1) d += __shfl_xor(d, o, 64);
     if (!ok || sub != 0) return;
-    if (a.gz) d += a.gz[i];
-    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    if (a.gz) d += a.gz[i] * a.gmul;
+    const float gs = (a.gscale ? a.gscale[0] : 1.f) * a.gmul;
     const float m = a.mu[i], v = a.lv[i], sd = expf(0.5f * v);
     float dmu = d, dlv = d * a.eps[i] * sd * 0.5f;
     if (a.add_kl) {
         const float k = gs * a.kld_weight / (float)a.B;
         dmu += k * m; dlv += k * 0.5f * (expf(v) - 1.f);
     }
-    if (a.gmu) dmu += a.gmu[i];
-    if (a.glv) dlv += a.glv[i];
+    if (a.gmu) dmu += a.gmu[i] * a.gmul;
+    if (a.glv) dlv += a.glv[i] * a.gmul;
     a.dlat[(size_t)b * 2 * a.L + l] = dmu; a.dlat[(size_t)b * 2 * a.L + a.L + l] = dlv;
 }
 // column sums of dlat -> fc_mu.bias / fc_var.bias gradients; one wave per column
-__global__ void colsum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ o0, float* __restrict__ o1, int split) {
+static __global__ void colsum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ o0, float* __restrict__ o1, int split, float scale) {
     const int j = blockIdx.x;
     float s = 0.f;
     for (int r = threadIdx.x; r < rows; r += 64) s += m[(size_t)r * cols + j];
-    s = wave_sum(s);
+    s = wave_sum(s) * scale;
     if (threadIdx.x == 0) { if (j < split) o0[j] = s; else o1[j - split] = s; }
 }
 
@@ -496,6 +510,7 @@ template <typename T> struct FcDgradArgs {
     const float* gpre;                          // optional external grad on pre_latents [B,F] (reference order)
     T* dz; double* stat; int B, F, L2, s2;
     int bt_per_wg;   // batch rows per workgroup (multiple of 16)
+    float gmul;      // scale of gpre (f16 gradient scaling; 1 otherwise)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
@@ -536,7 +551,7 @@ __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
             if (b < a.B) {
                 const size_t idx = (size_t)b * a.F + fp;
                 float da = acc[bb];
-                if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(fp, a.s2)];
+                if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(fp, a.s2)] * a.gmul;
                 const float z = yv[bb] * sc + sh;
                 const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
                 a.dz[idx] = fromfloat<T>(dzv);
@@ -613,12 +628,20 @@ __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int bb = 0; bb < BT; ++bb) acc[bb] = bias;
     const float* wrow = wd + (size_t)fr * L;
-    for (int l = 0; l < L; l += 4) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + l);
+    if ((L & 3) == 0) {
+        for (int l = 0; l < L; l += 4) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + l);
 #pragma unroll
-        for (int bb = 0; bb < BT; ++bb) {
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[bb * L + l]);
-            acc[bb] += zz[0] * w[0] + zz[1] * w[1] + zz[2] * w[2] + zz[3] * w[3];
+            for (int bb = 0; bb < BT; ++bb) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(&z_s[bb * L + l]);
+                acc[bb] += zz[0] * w[0] + zz[1] * w[1] + zz[2] * w[2] + zz[3] * w[3];
+            }
+        }
+    } else {   // latent sizes that are not a multiple of 4 (the reference's default is 10): rows are not 16-byte aligned
+        for (int l = 0; l < L; ++l) {
+            const float w = wrow[l];
+#pragma unroll
+            for (int bb = 0; bb < BT; ++bb) acc[bb] += z_s[bb * L + l] * w;
         }
     }
 #pragma unroll
@@ -672,12 +695,6 @@ __global__ __launch_bounds__(256) void decin_wgrad_kernel(const T* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // weight packing: f32 reference layouts -> MFMA B-operand images [tap][K/8][N][8] of T
-struct PackDesc {
-    const float* src; const float* src2; void* dst;
-    int kind;     // 0 conv [A][Bc][9]; 1 fc (mu|var -> [F/8][npad][8]); 2 decoder_input; 3 tap-major f32 copy [9][C]
-    int A, Bc, k_is_first, npad, L, s2;
-    long n;       // elements of dst
-};
 template <typename T>
 __global__ void pack_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
@@ -729,7 +746,7 @@ struct AdamArgs {
     AdamGroup grp[2]; int ngrp;
     float beta2, eps, weight_decay, grad_scale; int step;
 };
-__global__ void adamw_kernel(AdamArgs a) {
+static __global__ void adamw_kernel(AdamArgs a) {
     const AdamGroup gr = a.grp[blockIdx.y];
     const double bc1 = 1.0 - pow((double)gr.beta1, (double)a.step), bc2 = 1.0 - pow((double)a.beta2, (double)a.step);
     const float step_size = (float)((double)gr.lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -744,4 +761,42 @@ __global__ void adamw_kernel(AdamArgs a) {
         p -= step_size * (m / denom);
         a.p[k] = p; a.m[k] = m; a.v[k] = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// counter-based generator restated in oracle/vae_oracle.py (splitmix64 of seed, stream, counter)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double counter_uniform(unsigned long long i, unsigned long long seed, unsigned long long stream) {
+    unsigned long long base = splitmix64(seed);
+    base = splitmix64(base ^ (stream * 0xD1342543DE82EF95ULL));
+    const unsigned long long bits = splitmix64(base + i * 0x2545F4914F6CDD1DULL);
+    return (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+// eps ~ N(0,1): Box-Muller on the counter generator (same as oracle.counter_normal(n, seed, 5))
+static __global__ void counter_normal_kernel(float* out, long n, unsigned long long seed, unsigned long long stream) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u1 = counter_uniform(i, seed, 2 * stream + 1000003ULL), u2 = counter_uniform(i, seed, 2 * stream + 1000004ULL);
+    out[i] = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * 3.14159265358979323846 * u2));
+}
+// o[0] = scale * sum over the STAT_R replicas of an accumulator slot
+static __global__ void accum_to_f32_kernel(const double* slot, float* o, float scale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int rep = 0; rep < STAT_R; ++rep) s += slot[rep * 8];
+        o[0] = (float)(s * (double)scale);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* in, float* out, long n, int C, int HW) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = i % C; const long pix = (i / C) % HW; const long b = i / ((long)C * HW);
+    out[(b * C + ch) * HW + pix] = tofloat(in[i]);
 }

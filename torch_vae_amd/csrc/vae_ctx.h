@@ -1,0 +1,155 @@
+// Host-side context of the VAE step: shared by the C-ABI translation unit (vae_api.hip) and the per-storage-type
+// translation units (impl_bf16.hip / impl_f16.hip / impl_f32.hip) that instantiate the templated launch code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/vae_step.h"
+
+int vae_set_error(const char* what, const char* why);   // vae_api.hip; message readable through vae_last_error()
+
+#include "common.cuh"
+
+#define LAUNCH_CHECK(name)                                                        \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) return vae_set_error(name, hipGetErrorString(_e)); \
+    } while (0)
+
+static const int kBnC[8] = {32, 64, 128, 256, 128, 64, 32, 32};
+static const float kSlope = 0.01f;   // nn.LeakyReLU() default (models.py:47,70,79)
+static const float kBnEps = 1e-5f;   // nn.BatchNorm2d default eps
+static const float kBnMom = 0.1f;    // nn.BatchNorm2d default momentum
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct Tiling { int lth, ltw, lTB, tiles_x, tiles_y; };
+static Tiling make_tiling(int Hs, int Ws, int pixels) {
+    const int tw = std::min(Ws, pixels >= 128 ? 16 : 8), th = std::min(Hs, pixels / tw), TB = pixels / (th * tw);
+    Tiling t; t.lth = ilog2(th); t.ltw = ilog2(tw); t.lTB = ilog2(TB); t.tiles_x = Ws / tw; t.tiles_y = Hs / th;
+    return t;
+}
+
+struct BnLayer {
+    int C, H, W;            // spatial size of the tensor this BN normalises
+    double* stat_f; double* stat_b; float* block; void* y; void* dz;
+    int p_gamma, p_beta, p_convw, p_convb;
+};
+
+// weight packing descriptors (pack_kernel, edge_kernels.cuh): f32 reference layouts -> MFMA B-operand images of T
+struct PackDesc {
+    const float* src; const float* src2; void* dst;
+    int kind;     // 0 conv [A][Bc][9]; 1 fc (mu|var -> [F/8][npad][8]); 2 decoder_input; 3 tap-major f32 copy [9][C]
+    int A, Bc, k_is_first, npad, L, s2;
+    long n;       // elements of dst
+};
+
+// split-K sizing of the weight-gradient kernels (vae_set_option knobs; slabs are sized at vae_create for the defaults).
+// Workgroup targets: weight gradients run beside the input-gradient chain; on a saturated GPU (large batch x image) few
+// workgroups keep them out of its way (-4 % step time at the bench workload), a small problem wants them everywhere.
+//   wide: 128x32-channel tiles on 8 waves where the low-res side has >= 128 channels (16-bit prefetching kernel)
+//   tile 1: 64x32 channel tiles (prefetching kernel) also where 64x64 would fit
+struct WgradKnobs { int wgs = 128, cap_mb = 48, tile = 1, wide = 1, wide_wgs = 128, small_wgs = 1024, mid8 = 0, force_simple = 0; };
+
+struct vae_ctx {
+    int H, L, maxB, dtype, gen, s, s2; int64_t F; int npad_fc, npad_di; size_t esz;
+    int64_t poff[VAE_NUM_PARAMS], psz[VAE_NUM_PARAMS], ptotal, bnoff[8], bnc[8], bntotal;
+    BnLayer lay[8];
+    void *d0, *dd0;
+    float *eps, *dlat, *dlogit, *dlogit2, *ident, *wout_t;
+    void* wp_fwd[8]; void* wp_dg[8];   // indexed by BN layer id (1..7); [0] unused
+    void *fcpack, *dipack;
+    PackDesc* d_descs; std::vector<PackDesc> h_descs; const float* packed_for;
+    float* slab; size_t slab_floats;
+    // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
+    static constexpr int NSIDE = 3, NFORK = 16;
+    hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
+    hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
+    void* nccl_comm = nullptr; int comm_rank = 0, comm_world = 0;   // RCCL communicator owned by the context (vae_comm.hip)
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_conv1_grid, use_fused_bn, knob_rev, knob_lean, walk_dir, bwd_dirty, bwd_half_done;
+    double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
+    double* generic_accum;                           // vae_elbo_generic on this context's device (per context, not process-global)
+    WgradKnobs wk;
+    // f16 storage: the backward runs on gradients multiplied by gmul (a power of two chosen per forward so that the stored
+    // dz stay inside the f16 range: the BCE mean makes them O(1/(B*H*W))); every parameter gradient is written times ginv.
+    // The backward is linear in the upstream gradient, so this changes no f32 result (powers of two are exact).  1 otherwise.
+    float gmul, ginv;
+    // last forward
+    int B; int trained; const float* x; float *xhat, *mu, *lv, *z;
+    int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_convout_bwd_grid, knob_down_per_cu, knob_nt_max, knob_pipe_max_cout, knob_ablate_b; long long* dbg_buf; char dbg_tag[32]; int dbg_epi; int64_t ws_bytes;
+    std::vector<void*> allocs;
+    // per-kernel timing (bench.py roofline): HIP events on the launch stream
+    int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; int side; }; std::vector<ProfRec> prof_recs;
+    hipStream_t cur_stream = nullptr;   // the caller's stream of the call in progress (profiling: tells critical-chain launches from side-stream ones)
+};
+
+// RAII: brackets the launches of one logical kernel with events when profiling is on.
+struct ProfScope {
+    vae_ctx* c; hipStream_t st; int idx;
+    ProfScope(vae_ctx* c_, const char* name, double bytes, double flops, hipStream_t st_) : c(c_), st(st_), idx(-1) {
+        if (!c || !c->prof) return;
+        vae_ctx::ProfRec r; r.name = std::string(name) + (c->tag ? std::string(" @") + c->tag : std::string()); r.bytes = bytes; r.flops = flops;
+        r.side = (c->cur_stream && st != c->cur_stream) ? 1 : 0;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, st);
+        c->prof_recs.push_back(r); idx = (int)c->prof_recs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, st); }
+};
+
+static inline size_t wgrad_slab_floats(const WgradKnobs& k, int B, int Hs, int Ws, int CA, int CB, int* nsplit_out, int* tps_out, int* WA_out, int* WB_out,
+                                       bool wide_ok = false, bool big = false) {
+    int WA, WB;
+    if (wide_ok && k.wide && CA >= 128 && k.tile == 1) { WA = 4; WB = 1; }
+    else if (CA >= 64 && CB >= 64 && k.tile == 0) { WA = 2; WB = 2; } else if (CA >= 64 && k.tile <= 1) { WA = 2; WB = 1; } else { WA = 1; WB = 1; }
+    Tiling t = make_tiling(Hs, Ws, WG_KP);
+    const int TB = 1 << t.lTB;
+    const int n_tiles = ((B + TB - 1) / TB) * t.tiles_x * t.tiles_y;
+    const int chan_tiles = (CA / (32 * WA)) * (CB / (32 * WB));
+    const size_t per = (size_t)9 * CA * CB;
+    int nsplit = std::max(1, (!big ? k.small_wgs : (WA == 4 ? k.wide_wgs : k.wgs)) / chan_tiles);
+    const size_t cap = ((size_t)k.cap_mb << 20) / 4;  // bound slab traffic to 48 MiB per layer
+    nsplit = (int)std::min<size_t>(nsplit, std::max<size_t>(1, cap / per));
+    nsplit = std::min(nsplit, n_tiles);
+    const int tps = (n_tiles + nsplit - 1) / nsplit;
+    nsplit = (n_tiles + tps - 1) / tps;
+    *nsplit_out = nsplit; *tps_out = tps; *WA_out = WA; *WB_out = WB;
+    return per * nsplit;
+}
+
+// side streams (vae_api.hip)
+struct SideFork { hipStream_t st; float* slab; int rc; };
+SideFork fork_side(vae_ctx* c, hipStream_t st, int which = -1);
+int join_sides(vae_ctx* c, hipStream_t st);
+int join_comm(vae_ctx* c, hipStream_t st);
+
+// entry points instantiated once per storage type (impl_bf16.hip, impl_f16.hip, impl_f32.hip)
+template <typename T> int pack_weights(vae_ctx* c, const float* params, hipStream_t st);
+template <typename T> int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
+                                       const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, hipStream_t st);
+template <typename T> int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* bn_running, int64_t* nbt, int train,
+                                      const float* x, float* xhat, hipStream_t st);
+template <typename T> int backward_impl(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,
+                                        const float* g_mu, const float* g_lv, const float* g_z, const float* g_pre, float kld_weight, int add_kl,
+                                        int part, hipStream_t st);
+template <typename T> int pre_latents_impl(vae_ctx* c, float* out, hipStream_t st);
+template <typename T> int debug_tensor_impl(vae_ctx* c, const void* src, float* out, long n, int C, int HW, hipStream_t st);
+
+#define VAE_INSTANTIATE(T)                                                                                                              \
+    template int pack_weights<T>(vae_ctx*, const float*, hipStream_t);                                                                  \
+    template int forward_impl<T>(vae_ctx*, const float*, int, const float*, float*, int64_t*, const float*, uint64_t, int, float*,     \
+                                 float*, float*, float*, hipStream_t);                                                                  \
+    template int decode_impl<T>(vae_ctx*, const float*, int, const float*, float*, int64_t*, int, const float*, float*, hipStream_t);  \
+    template int backward_impl<T>(vae_ctx*, const float*, const float*, float*, const float*, const float*, const float*, const float*, \
+                                  const float*, const float*, float, int, int, hipStream_t);                                            \
+    template int pre_latents_impl<T>(vae_ctx*, float*, hipStream_t);                                                                    \
+    template int debug_tensor_impl<T>(vae_ctx*, const void*, float*, long, int, int, hipStream_t);
+
+// storage-type dispatch: VAE_DISPATCH(c->dtype, forward_impl, (c, ...))
+#define VAE_DISPATCH(dtype, fn, args) ((dtype) == VAE_DTYPE_BF16 ? fn<bf16> args : (dtype) == VAE_DTYPE_F16 ? fn<f16> args : fn<float> args)

@@ -32,11 +32,17 @@ from . import _lib
 from .types_helpers import EncoderOutput, LossOutput, ModelOutput
 
 _DTYPES = {"f32": _lib.DTYPE_F32, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32,
-           "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16}
+           "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16,
+           "f16": _lib.DTYPE_F16, "fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16, "half": _lib.DTYPE_F16}
 
 
-def _stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 class _Context:
@@ -63,14 +69,21 @@ class _VAEForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, model, eps):
         ctx.set_materialize_grads(False)
-        ctx.model = model
+        ctx.model_ref = weakref.ref(model)      # no model -> _last -> grad_fn -> model reference cycle
         out = model._run_forward(x, eps, train=model.training)
+        ctx.generation = model._fwd_count       # the activations saved for backward live in the context, not in the graph
         handle = torch.zeros((), device=x.device, dtype=torch.float32)
         return (*out, handle)
 
     @staticmethod
     def backward(ctx, g_xhat, g_mu, g_lv, g_z, g_pre, g_handle):
-        ctx.model._run_backward(g_xhat, g_mu, g_lv, g_z, g_pre, g_handle)
+        model = ctx.model_ref()
+        if model is None:
+            raise RuntimeError("the VanillaVAE of this graph no longer exists")
+        if model._fwd_count != ctx.generation:
+            raise RuntimeError("backward through a forward that is no longer the model's last one: the context keeps the "
+                               "activations of one forward only (run backward before the next forward, or one model per graph)")
+        model._run_backward(g_xhat, g_mu, g_lv, g_z, g_pre, g_handle)
         return None, None, None, None
 
 
@@ -80,7 +93,8 @@ class _FusedELBO(torch.autograd.Function):
     @staticmethod
     def forward(ctx, handle, model, kld_weight):
         out3 = torch.empty(3, device=handle.device, dtype=torch.float32)
-        _lib.check(_lib.lib().vae_loss(model._ctx.handle, float(kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss")
+        with torch.cuda.device(handle.device):
+            _lib.check(_lib.lib().vae_loss(model._ctx.handle, float(kld_weight), out3.data_ptr(), _stream_ptr(handle.device)), "vae_loss")
         model._bwd_kld_weight = float(kld_weight)
         ctx.mark_non_differentiable(out3)
         return out3[0].clone(), out3
@@ -98,10 +112,11 @@ class _GenericELBO(torch.autograd.Function):
         xhat, target, mu, lv = (t.contiguous().float() for t in (xhat, target, mu, lv))
         out3 = torch.empty(3, device=xhat.device, dtype=torch.float32)
         gx, gm, gl = torch.empty_like(xhat), torch.empty_like(mu), torch.empty_like(lv)
-        _lib.check(_lib.lib().vae_elbo_generic(xhat.data_ptr(), target.data_ptr(), mu.data_ptr(), lv.data_ptr(),
-                                              xhat.numel(), mu.shape[0], mu.shape[1], float(kld_weight),
-                                              out3.data_ptr(), gx.data_ptr(), gm.data_ptr(), gl.data_ptr(),
-                                              _stream_ptr()), "vae_elbo_generic")
+        with torch.cuda.device(xhat.device):
+            _lib.check(_lib.lib().vae_elbo_generic(xhat.data_ptr(), target.data_ptr(), mu.data_ptr(), lv.data_ptr(),
+                                                  xhat.numel(), mu.shape[0], mu.shape[1], float(kld_weight),
+                                                  out3.data_ptr(), gx.data_ptr(), gm.data_ptr(), gl.data_ptr(),
+                                                  _stream_ptr(xhat.device)), "vae_elbo_generic")
         ctx.save_for_backward(gx, gm, gl)
         ctx.mark_non_differentiable(out3)
         return out3[0].clone(), out3
@@ -276,7 +291,8 @@ class VanillaVAE(nn.Module):
         back at the end of the backward's second half (include/vae_step.h: vae_comm_stream)."""
         import ctypes as C
         out = C.c_void_p()
-        _lib.check(_lib.lib().vae_comm_stream(self._ctx.handle, _stream_ptr(), C.byref(out)), "vae_comm_stream")
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_comm_stream(self._ctx.handle, self._stream(), C.byref(out)), "vae_comm_stream")
         return torch.cuda.ExternalStream(out.value, device=self._flat.device)
 
     def _require_device(self):
@@ -284,13 +300,69 @@ class VanillaVAE(nn.Module):
             raise RuntimeError("VanillaVAE (MI355X) runs only on a HIP device: call model.to('cuda') first; "
                                "there is no CPU path.")
 
+    def _device_guard(self):
+        """Every library call runs with the MODEL's device current: vae_create allocates its workspace on the current
+        HIP device and kernels launch on the stream passed in, which must belong to the device that owns the tensors."""
+        return torch.cuda.device(self._flat.device)
+
+    def _stream(self):
+        return _stream_ptr(self._flat.device)
+
     def _context(self, batch: int) -> _Context:
         need = max(batch, self._max_batch or 0)
         if self._ctx is None or self._ctx.key[2] < batch:
             self._ctx = None
-            self._ctx = _Context(self.img_size, self.latent_dim, need, _DTYPES[self.compute_dtype], self.generalised)
+            with self._device_guard():
+                self._ctx = _Context(self.img_size, self.latent_dim, need, _DTYPES[self.compute_dtype], self.generalised)
+                if getattr(self, "_want_lib_comm", False):
+                    self._init_library_comm()
             self._max_batch = need
         return self._ctx
+
+    # -- data parallel: the step library's own RCCL communicator (include/vae_step.h: vae_comm_*) ----------------------
+    def _init_library_comm(self):
+        """COLLECTIVE over torch.distributed's default group: rank 0 draws the RCCL unique id, the process group carries it
+        to the other ranks, every rank creates its communicator.  On failure the model falls back to torch.distributed's
+        collectives (and says so once)."""
+        import ctypes as C
+        import warnings
+        import torch.distributed as dist
+        L = _lib.lib()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        ok = True
+        if rank == 0:
+            ok = L.vae_comm_unique_id(buf) == 0
+        box = [bytes(buf.raw) if ok else None]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None or L.vae_comm_init(self._ctx.handle, rank, world, C.create_string_buffer(box[0], _lib.COMM_ID_BYTES)) != 0:
+            warnings.warn("torch_vae_amd: RCCL communicator of the step library unavailable ("
+                          + L.vae_last_error().decode() + "); gradients go through torch.distributed instead")
+            self._want_lib_comm = False
+
+    def library_comm_world(self) -> int:
+        """World size of the context's own RCCL communicator (0: none, gradients go through torch.distributed)."""
+        if self._ctx is None or not self._ctx.handle:
+            return 0
+        return int(_lib.lib().vae_comm_world(self._ctx.handle))
+
+    def allreduce_ranges(self, prefixes, on_comm_stream: bool = False, average: bool = True):
+        """Mean (or sum) all-reduce of the flat-gradient ranges of the named parameter groups through the library's
+        communicator, as ONE RCCL group, on the current stream or on the context's communication stream (which is ordered
+        after everything enqueued so far and joined back by the second half of the backward)."""
+        import ctypes as C
+        L = _lib.lib()
+        rngs = [self.group_range(p) for p in prefixes]
+        offs = (C.c_int64 * len(rngs))(*[r[0] for r in rngs])
+        sizes = (C.c_int64 * len(rngs))(*[r[1] for r in rngs])
+        with self._device_guard():
+            st = self._stream()
+            if on_comm_stream:
+                out = C.c_void_p()
+                _lib.check(L.vae_comm_stream(self._ctx.handle, st, C.byref(out)), "vae_comm_stream")
+                st = out.value
+            _lib.check(L.vae_allreduce_grads(self._ctx.handle, self._gflat.data_ptr(), len(rngs), offs, sizes, int(average), st),
+                       "vae_allreduce_grads")
 
     # -- kernels ------------------------------------------------------------
     def set_next_eps(self, eps: Tensor | None):
@@ -319,17 +391,21 @@ class VanillaVAE(nn.Module):
             if eps.shape != (B, L):
                 raise RuntimeError(f"eps must be [{B},{L}]")
         self._fwd_count += 1
-        _lib.check(_lib.lib().vae_forward(
-            ctx.handle, x.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(), self._nbt.data_ptr(),
-            _lib.ptr(eps), int(self.eps_seed) + self._fwd_count, int(train), xhat.data_ptr(), mu.data_ptr(),
-            lv.data_ptr(), z.data_ptr(), _stream_ptr()), "vae_forward")
-        if want_pre is None:
-            want_pre = self.materialize_pre_latents
-        if want_pre:
-            pre = torch.empty(B, self.flattened_size, device=dev)
-            _lib.check(_lib.lib().vae_pre_latents(ctx.handle, pre.data_ptr(), _stream_ptr()), "vae_pre_latents")
-        else:
-            pre = torch.empty(B, 0, device=dev)
+        # seed of the device-side reparameterisation noise (used when eps is None): distinct per step AND per rank, so
+        # data-parallel replicas draw independent noise like the reference's per-process torch generator (models.py:182)
+        seed = (int(self.eps_seed) + self._fwd_count + _rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_forward(
+                ctx.handle, x.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(), self._nbt.data_ptr(),
+                _lib.ptr(eps), seed, int(train), xhat.data_ptr(), mu.data_ptr(),
+                lv.data_ptr(), z.data_ptr(), self._stream()), "vae_forward")
+            if want_pre is None:
+                want_pre = self.materialize_pre_latents
+            if want_pre:
+                pre = torch.empty(B, self.flattened_size, device=dev)
+                _lib.check(_lib.lib().vae_pre_latents(ctx.handle, pre.data_ptr(), self._stream()), "vae_pre_latents")
+            else:
+                pre = torch.empty(B, 0, device=dev)
         self._last = dict(x=x, xhat=xhat, mu=mu, lv=lv, z=z, train=train)
         return xhat, mu, lv, z, pre
 
@@ -340,10 +416,11 @@ class VanillaVAE(nn.Module):
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         g_xhat, g_mu, g_lv, g_z, g_pre, g_handle = map(c, (g_xhat, g_mu, g_lv, g_z, g_pre, g_handle))
         target = self._gflat if into_gflat else self._gnew
-        _lib.check(_lib.lib().vae_backward(
-            self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), target.data_ptr(), _lib.ptr(g_xhat),
-            _lib.ptr(g_handle), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_z), _lib.ptr(g_pre),
-            float(self._bwd_kld_weight), int(g_handle is not None), _stream_ptr()), "vae_backward")
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_backward(
+                self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), target.data_ptr(), _lib.ptr(g_xhat),
+                _lib.ptr(g_handle), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_z), _lib.ptr(g_pre),
+                float(self._bwd_kld_weight), int(g_handle is not None), self._stream()), "vae_backward")
         if not into_gflat:
             self._commit_grads()
 
@@ -402,8 +479,9 @@ class VanillaVAE(nn.Module):
         B = z.shape[0]
         ctx = self._context(B)
         xhat = torch.empty(B, 1, self.img_size, self.img_size, device=z.device, dtype=torch.float32)
-        _lib.check(_lib.lib().vae_decode(ctx.handle, z.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(),
-                                        self._nbt.data_ptr(), int(self.training), xhat.data_ptr(), _stream_ptr()), "vae_decode")
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_decode(ctx.handle, z.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(),
+                                            self._nbt.data_ptr(), int(self.training), xhat.data_ptr(), self._stream()), "vae_decode")
         self._last = None
         return xhat
 
@@ -445,7 +523,8 @@ class VanillaVAE(nn.Module):
             loss, out3 = _FusedELBO.apply(last["handle"], self, self.kld_weight)
         elif last is not None and output["output"] is last.get("out_ref") and last.get("handle") is None:
             out3 = torch.empty(3, device=last["xhat"].device)
-            _lib.check(_lib.lib().vae_loss(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss")
+            with self._device_guard():
+                _lib.check(_lib.lib().vae_loss(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), self._stream()), "vae_loss")
             loss = out3[0].clone()
         else:
             loss, out3 = _GenericELBO.apply(output["output"], output["input"], output["encoded"]["mu"],
@@ -476,13 +555,15 @@ class VanillaVAE(nn.Module):
         xhat, mu, lv, z, _ = self._run_forward(x, eps, train=True, want_pre=False)
         out3 = torch.empty(3, device=x.device, dtype=torch.float32)
         # the ELBO scalars are only read after the step: finalised beside the backward (joined by it), not in front of it
-        _lib.check(_lib.lib().vae_loss_deferred(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), _stream_ptr()), "vae_loss_deferred")
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_loss_deferred(self._ctx.handle, float(self.kld_weight), out3.data_ptr(), self._stream()), "vae_loss_deferred")
         self._bwd_kld_weight = float(self.kld_weight)
         last = self._last
         for part in ((0,) if on_decoder_grads is None else (1, 2)):
-            _lib.check(_lib.lib().vae_backward_part(
-                self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), self._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
-                float(self.kld_weight), 1, part, _stream_ptr()), "vae_backward")
+            with self._device_guard():
+                _lib.check(_lib.lib().vae_backward_part(
+                    self._ctx.handle, last["x"].data_ptr(), self._flat.data_ptr(), self._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
+                    float(self.kld_weight), 1, part, self._stream()), "vae_backward")
             if part == 1:
                 self.bind_flat_grads()
                 on_decoder_grads()

@@ -16,7 +16,10 @@ from . import _lib
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        # (the inert keys are torch.optim.AdamW's: checkpoints written by either optimiser then carry the same param_group
+        #  keys and load into the other, reference train.py:320-329)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
         super().__init__(params, defaults)
         self._model = None
         self._m = self._v = None
@@ -100,10 +103,12 @@ class FusedAdamW(torch.optim.Optimizer):
         for g, _ in active:
             if (g["betas"][1], g["eps"], g["weight_decay"]) != (g0["betas"][1], g0["eps"], g0["weight_decay"]):
                 raise NotImplementedError("groups must share beta2, eps and weight_decay")
-        _lib.check(_lib.lib().vae_adamw_step(
-            model.flat_parameters().data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n, offs, sizes,
-            lrs, b1s, float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(self.grad_scale),
-            self._step, torch.cuda.current_stream().cuda_stream), "vae_adamw_step")
+        dev = gflat.device
+        with torch.cuda.device(dev):   # launch on the model's device, whatever the caller's current device is
+            _lib.check(_lib.lib().vae_adamw_step(
+                model.flat_parameters().data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n, offs, sizes,
+                lrs, b1s, float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(self.grad_scale),
+                self._step, torch.cuda.current_stream(dev).cuda_stream), "vae_adamw_step")
         for g, _ in active:
             for p in g["params"]:
                 self.state[p]["step"] += 1

@@ -46,6 +46,9 @@ def build_optimizer(config, model, steps_per_epoch: int):
         raise NotImplementedError(f"Scheduler {config.scheduler} not supported.")
     scheduler = torch.optim.lr_scheduler.OneCycleLR(
         optimizer, [p["lr"] for p in optimizer.param_groups], epochs=config.epochs, steps_per_epoch=steps_per_epoch)
+    if _dist_active() and isinstance(model, VanillaVAE) and world > 1:
+        sync_initial_state(model)            # every replica starts from rank 0's weights / BatchNorm buffers
+        enable_library_allreduce(model)      # RCCL from inside the step library where every rank owns a GPU
     return optimizer, scheduler
 
 
@@ -57,50 +60,82 @@ def _dist_active() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def sync_initial_state(model: VanillaVAE, src: int = 0):
+    """Identical replicas before the first step: broadcast rank `src`'s flat parameters, BatchNorm running statistics and
+    counters.  The reference never needs this (one process); data parallelism does - ranks that construct their
+    model under different RNG states would otherwise average gradients of different networks."""
+    if not _dist_active() or model._flat is None:
+        return
+    for t in (model._flat, model._bnflat, model._nbt):
+        dist.broadcast(t, src=src)
+
+
+def enable_library_allreduce(model: VanillaVAE) -> bool:
+    """Ask the model to exchange gradients through the step library's own RCCL communicator (include/vae_step.h:
+    vae_comm_init / vae_allreduce_grads) instead of torch.distributed's: the collective is then enqueued by the library on
+    the stream it names, between its own kernels.  Only with the "nccl" (= RCCL) backend - every rank needs its own GPU.
+    The communicator is created with the context (collectively, on every rank's first forward)."""
+    if not _dist_active() or dist.get_backend() != "nccl" or os.environ.get("VAE_DP_LIBRARY_COMM", "1") == "0":
+        return False
+    model._want_lib_comm = True
+    return True
+
+
 def _allreduce_range(model: VanillaVAE, prefix: str):
-    """In-line (synchronous-op) all-reduce of one gradient range: torch enqueues the RCCL kernel on the CURRENT stream,
-    so it is ordered by the stream itself.  (Asynchronous ops go through ProcessGroupNCCL's own stream and two
-    event hand-offs, measured at ~0.25 ms per collective on MI355X once the streams sit on different hardware queues.)"""
+    """torch.distributed fallback (gloo rehearsals, or RCCL through ProcessGroupNCCL when the library communicator is
+    unavailable): in-line synchronous op, so torch enqueues it on the CURRENT stream (asynchronous ops go through
+    ProcessGroupNCCL's own stream and two event hand-offs, measured at ~0.25 ms per collective on MI355X).  Leaves the
+    MEAN over ranks in the gradient buffer."""
     g = model.flat_grads()
     off, n = model.group_range(prefix)
-    dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=False)
+    world = _dp_world()
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(g[off:off + n], op=dist.ReduceOp.AVG, async_op=False)
+    else:
+        dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=False)
+        if world > 1:
+            g[off:off + n].mul_(1.0 / world)
+
+
+def _reduce(model: VanillaVAE, prefixes, on_comm_stream: bool = False):
+    """Mean all-reduce of the named gradient ranges: the library's communicator when every rank has one, else torch's."""
+    if model.library_comm_world() == _dp_world():
+        model.allreduce_ranges(prefixes, on_comm_stream=on_comm_stream)
+        return
+    with (torch.cuda.stream(model.comm_stream()) if on_comm_stream else nullcontext()):
+        for prefix in prefixes:
+            _allreduce_range(model, prefix)
 
 
 def allreduce_gradients(model: VanillaVAE, optimizer=None):
-    """Sum the optimised gradient ranges over ranks (RCCL all-reduce over xGMI) on the current stream; the mean is
-    applied inside the AdamW kernel (grad_scale = 1/world).  Returns [] (kept for callers that wait on handles)."""
-    world = _dp_world()
-    if world == 1 and not _dist_active():
-        return []
-    for prefix in ("decoder", "encoder"):  # decoder gradients are produced first
-        _allreduce_range(model, prefix)
-    if optimizer is not None and hasattr(optimizer, "grad_scale"):
-        optimizer.grad_scale = 1.0 / world
+    """Average the optimised gradient ranges over ranks (RCCL all-reduce over xGMI) on the current stream: afterwards
+    ``param.grad`` holds the mean over replicas, the reference's single-process semantics at the global batch (up to
+    per-replica BatchNorm).  Returns [] (kept for callers that wait on handles)."""
+    if _dist_active():
+        _reduce(model, ("decoder", "encoder"))   # decoder gradients are produced first
     return []
 
 
 def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool = True, overlap: bool | None = None):
     """One training step on the fused path (train.py:634-656): forward, ELBO, backward, [gradient all-reduce], AdamW.
-    Data parallel: both gradient buckets are reduced in line on the compute stream after the backward (no stream
-    hand-offs).  ``overlap=True`` (or VAE_DP_OVERLAP=1) instead enqueues the decoder bucket on the context's
-    communication stream between the two halves of the backward so that it overlaps the encoder half; on the single
-    MI355X available during development the hand-off to a second stream cost more than it hid, so it is opt-in."""
-    if overlap is None:
-        overlap = os.environ.get("VAE_DP_OVERLAP", "0") == "1"
+    Data parallel with the library communicator (the product path on a multi-GPU node): ``overlap`` puts the decoder
+    bucket's all-reduce on the context's communication stream between the two halves of the backward, so that it runs
+    under the encoder half; the encoder bucket follows in line on the compute stream, directly in front of the AdamW
+    kernel.  ``overlap=False`` issues both buckets as one RCCL group after the backward.  Default: overlap with the
+    library communicator, in line through torch.distributed (whose stream hand-offs cost more than they hide);
+    VAE_DP_OVERLAP=0/1 overrides."""
     if not _dist_active():
         out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
     else:
+        if overlap is None:
+            overlap = os.environ.get("VAE_DP_OVERLAP", "1" if getattr(model, "_want_lib_comm", False) else "0") == "1"
         if overlap:
-            def decoder_bucket():
-                with torch.cuda.stream(model.comm_stream()):
-                    _allreduce_range(model, "decoder")
-            out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps, on_decoder_grads=decoder_bucket)
+            out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps,
+                                                      on_decoder_grads=lambda: _reduce(model, ("decoder",), on_comm_stream=True))
+            _reduce(model, ("encoder",))
         else:
             out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
-            _allreduce_range(model, "decoder")
-        _allreduce_range(model, "encoder")
-        if hasattr(optimizer, "grad_scale"):
-            optimizer.grad_scale = 1.0 / _dp_world()
+            _reduce(model, ("decoder", "encoder"))
     optimizer.step()
     return out3, xhat
 
@@ -133,8 +168,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
             loss_output = criterion(output)
             loss_output["loss"].backward()
             if isinstance(model, VanillaVAE):
-                for w in allreduce_gradients(model, optimizer):
-                    w.wait()
+                allreduce_gradients(model, optimizer)
             optimizer.step()
             out3 = torch.stack([loss_output["loss"].detach(), loss_output["reconstruction_loss"].detach(),
                                 loss_output["kld_loss"].detach()])
