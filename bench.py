@@ -248,7 +248,7 @@ def main():
     else:
         if args.dump_order and seq is not None:
             json.dump(seq[:len(seq) // nprof], open(args.dump_order, "w"))
-        dom = kernels[0]
+        dom = next((k for k in kernels if k["bytes"] > 0), kernels[0])   # (skip zero-byte bookkeeping launches)
         ach = dom["gbs"]
         # algorithmic bytes of every launch overlapping the dominant launch's windows / total window time
         wbytes, wtime, mates = 0.0, 0.0, set()

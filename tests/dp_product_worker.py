@@ -63,8 +63,10 @@ for s in range(STEPS):
     ref = flat.clone(); dist.broadcast(ref, 0)
     assert torch.equal(flat, ref), f"replicas diverged at step {s}"
     # .grad holds the MEAN over replicas (what a caller of the reference's single-process loop would see at the global batch)
-    g = model.flat_grads().detach().clone(); gr = g.clone(); dist.broadcast(gr, 0)
-    assert torch.equal(g, gr)
+    for prefix in ("encoder", "decoder"):
+        off, n = model.group_range(prefix)
+        g = model.flat_grads()[off:off + n].detach().clone(); gr = g.clone(); dist.broadcast(gr, 0)
+        assert torch.equal(g, gr), f"{prefix} gradients differ between ranks after the exchange"
 
 # oracle: R replicas simulated in one process (f64)
 tr = vo.make_trainer(L, H, B, TOTAL, seed=SEED, world_size=world)

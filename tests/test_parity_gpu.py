@@ -5,11 +5,11 @@ fixtures generated from the reference.  Tolerances:
                     one pre-activation within rounding distance of 0 (binary inputs make exact ties
                     common) flips a derivative and moves a whole gradient by ~1e-3, so gradient
                     checks allow 5e-3 ("kink ties").
-  bf16 kernel mode: ELBO scalars <= 1e-2 relative (reference's own bf16 autocast gap is 4.4e-3, SURVEY.md H4);
-                    gradients per tensor rel-L2 <= GRAD_TOL["bf16"] against the fp64 oracle.
-  f16 kernel mode : ELBO scalars <= 2e-3, gradients rel-L2 <= GRAD_TOL["f16"] (10 mantissa bits instead of 7).
-The 16-bit bounds are what the kernels measure on MI355X (every run appends its measured gaps to
-gpurun_out/parity_report.jsonl) plus headroom, not a cosine: a gradient within them has the right direction AND size.
+  bf16 kernel mode: ELBO scalars <= 1e-2 relative (measured <= 5.3e-3; the reference's own bf16 autocast gap is 4.4e-3,
+                    SURVEY.md H4); gradients: see GRAD_TOL / GRAD_TOL_FULL / GRAD_TOL_FIXTURE below.
+  f16 kernel mode : ELBO scalars <= 2e-3 (measured <= 6.3e-4), gradients likewise (10 mantissa bits instead of 7).
+The 16-bit bounds are what the kernels measure on MI355X plus headroom (every run appends its measured gaps to
+gpurun_out/parity_report.jsonl); they bound direction AND size of every gradient tensor.
 """
 import json
 import os
@@ -25,7 +25,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ELBO_TOL = {"f32": 1e-4, "bf16": 1e-2, "f16": 2e-3}
-GRAD_TOL = {"f32": 5e-3, "bf16": 6e-2, "f16": 1.5e-2}     # per-tensor rel-L2 vs the fp64 oracle
+# per-tensor gradient rel-L2 vs the fp64 oracle.  16-bit storage of the pre-activations flips LeakyReLU's slope for the
+# elements that sit within one rounding step of zero (the gradient is discontinuous there, factor 100): the error of a
+# gradient tensor is ~sqrt(fraction of flipped elements), independent of how many pixels it sums over.  Measured on MI355X
+# over the adversarial small cases below (non-trivial BatchNorm affine, batches of 1-33): bf16 0.11-0.21, f16 0.03-0.10;
+# at the BASELINE workload sizes the whole flat gradient agrees with the f32 mode to 6e-3 (bf16) / 2.4e-3 (f16) - gated in
+# test_full_size_baseline_configs - and the reference-initialised fixtures to 5e-2 / 3e-2 per tensor norm.
+GRAD_TOL = {"f32": 5e-3, "bf16": 0.28, "f16": 0.14}
+GRAD_TOL_FULL = {"bf16": 2e-2, "f16": 8e-3}              # flat gradient vs the f32 mode at full size
+GRAD_TOL_FIXTURE = {"bf16": 8e-2, "f16": 4e-2}           # per-tensor gradient NORM vs the reference fixture
 FWD_TOL = {"f32": 1e-4, "bf16": 2e-2, "f16": 3e-3}        # xhat rel-L2
 
 
@@ -85,7 +93,8 @@ def test_f32_step0_matches_reference_fixture(name):
                                  # latent sizes whose padded widths are not a power-of-two number of 32-column blocks
                                  # (npad 96 / 160 / 192: the dense kernel's N tiling) and sizes that are not a multiple of 4
                                  (32, 40, 3, False), (32, 48, 5, False), (32, 80, 3, False), (32, 96, 4, False), (64, 160, 2, True),
-                                 (32, 10, 6, False), (64, 10, 2, True), (32, 1, 3, False), (32, 3, 9, False)])
+                                 (32, 10, 6, False), (64, 10, 2, True), (32, 1, 3, False), (32, 3, 9, False),
+                                 (32, 16, 256, False), (64, 16, 48, True)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_every_tensor_against_oracle(cfg, dtype):
     """All gradients (full tensors) against the fp64 oracle, with non-trivial BN affine/bias values,
@@ -110,11 +119,8 @@ def test_every_tensor_against_oracle(cfg, dtype):
     np.testing.assert_allclose(got3, want, rtol=ELBO_TOL[dtype])
     assert rel_l2(xhat.cpu().numpy(), c["output"]) < FWD_TOL[dtype]
     assert rel_l2(model._last["mu"].cpu().numpy(), c["mu"]) < 1.5 * FWD_TOL[dtype]
-    # a single sample at the 2x2 bottleneck gives BatchNorm four values per channel: the f64 gradient itself is
-    # ill-conditioned there (near-zero variances), so the 16-bit bound is only meaningful from two samples up
-    tol = GRAD_TOL[dtype] * (4.0 if (dtype != "f32" and B * (H // 16) ** 2 < 16) else 1.0)
     for n, gap in gaps.items():
-        assert gap < tol, (n, gap)
+        assert gap < GRAD_TOL[dtype], (n, gap)
 
 
 def test_tr16_and_scalar_wgrad_agree():
@@ -655,9 +661,8 @@ def test_16bit_step0_against_reference_fixture(name, dtype):
     assert rel_l2(model._last["mu"].cpu().numpy(), gold["mu"]) < 1.5 * FWD_TOL[dtype]
     xh = xhat.double().cpu().numpy()
     assert abs(xh.sum() / float(gold["output_sum"]) - 1) < FWD_TOL[dtype]
-    # B = 2 at the bottleneck gives BatchNorm few values per channel, hence the looser norm bound than GRAD_TOL
     for n, gap in norm_gap.items():
-        assert gap < 4 * GRAD_TOL[dtype], (n, gap)
+        assert gap < GRAD_TOL_FIXTURE[dtype], (n, gap)
 
 
 FULL = [
@@ -714,7 +719,7 @@ def test_full_size_baseline_configs(cfg):
         ggap = float((g1.double() - gref).norm() / gref.norm())
         report(test="full_size", cfg=list(cfg), elbo_rel_vs_f32=gap, flat_grad_rel_l2_vs_f32=ggap)
         assert gap < ELBO_TOL[dtype]
-        assert ggap < 2 * GRAD_TOL[dtype]
+        assert ggap < GRAD_TOL_FULL[dtype]
 
 
 def test_bce_edges_and_saturating_logits_on_hip():
@@ -736,22 +741,23 @@ def test_bce_edges_and_saturating_logits_on_hip():
     H, L, B = 32, 16, 4
     x = vo.synth_pianoroll(B, H, 3)
     eps = vo.counter_normal(B * L, 3, 5).reshape(B, L)
-    for bias in (150.0, -150.0, 30.0):
+    # (bias 30 saturates f32 too: sigmoid(30) rounds to exactly 1.0f, as in the reference's f32 arithmetic; bias 8 does not)
+    for bias in (150.0, -150.0, 30.0, 8.0):
         p = perturbed_params(L, H, 4, False)
         p["final_layer.3.bias"] = np.array([bias])
         c = vo.forward({k: v.astype(np.float32) for k, v in p.items()}, x.astype(np.float32), eps.astype(np.float32), None, train=True)
-        want = vo.loss(c)
-        want64 = vo.loss(vo.forward(p, x.astype(np.float64), eps, None, train=True))
+        want = vo.loss(c)     # the oracle in f32, the reference's arithmetic: saturation happens where f32 saturates
         for dtype in ("f32", "bf16", "f16"):
             m = make_model(H, L, False, dtype, p)
             out3, xhat = m.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
             assert bool(torch.isfinite(m.flat_grads()).all())
-            if abs(bias) > 100:
-                # f32 sigmoid saturates: the loss is count(mismatching pixels) * 100 / N exactly as ATen's clamp gives it
+            if abs(bias) > 20:
+                # the loss is count(mismatching pixels) * 100 / N exactly, as ATen's log clamp gives it
                 np.testing.assert_allclose(out3[1].item(), float(want["reconstruction_loss"]), rtol=1e-5)
                 assert float(xhat.max()) == float(xhat.min()) == (1.0 if bias > 0 else 0.0)
+                assert float(want["reconstruction_loss"]) > 5.0
             else:
-                np.testing.assert_allclose(out3[1].item(), float(want64["reconstruction_loss"]), rtol=ELBO_TOL[dtype])
+                np.testing.assert_allclose(out3[1].item(), float(want["reconstruction_loss"]), rtol=ELBO_TOL[dtype] if dtype != "f32" else 2e-4)
 
 
 def test_wgrad_64bit_offset_fallback_agrees():
@@ -883,7 +889,7 @@ def test_data_parallel_product_path_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "tests", "dp_product_worker.py"), ROOT]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(ln for ln in r.stderr.splitlines() if "rank" in ln or "Error" in ln or "assert" in ln)[-6000:]
     assert r.stdout.count("DP_PRODUCT_OK") == 2
 
 

@@ -247,7 +247,7 @@ extern "C" int vae_forward(vae_ctx* c, const float* x, int B, const float* param
     if (B < 1 || B > c->maxB) return vae_set_error("vae_forward", "batch exceeds the context's max_batch");
     if (!x || !params || !xhat || !mu || !lv || !z) return vae_set_error("vae_forward", "null tensor pointer");
     hipStream_t st = (hipStream_t)stream;
-    c->cur_stream = st;
+    c->cur_stream = st; c->cur_stream_set = true;
     return VAE_DISPATCH(c->dtype, forward_impl, (c, x, B, params, bn_running, nbt, eps, seed, train, xhat, mu, lv, z, st));
 }
 
@@ -329,7 +329,7 @@ extern "C" int vae_backward_part(vae_ctx* c, const float* x, const float* params
     if (!c) return vae_set_error("vae_backward", "null ctx");
     if (!x || !params || !grads) return vae_set_error("vae_backward", "null tensor pointer");
     hipStream_t st = (hipStream_t)stream;
-    c->cur_stream = st;
+    c->cur_stream = st; c->cur_stream_set = true;
     return VAE_DISPATCH(c->dtype, backward_impl, (c, x, params, grads, g_xhat, gscale, g_mu, g_lv, g_z, g_pre, kld_weight, add_kl, part, st));
 }
 extern "C" int vae_backward(vae_ctx* c, const float* x, const float* params, float* grads, const float* g_xhat, const float* gscale,

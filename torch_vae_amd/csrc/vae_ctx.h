@@ -86,7 +86,7 @@ struct vae_ctx {
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
     int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; int side; }; std::vector<ProfRec> prof_recs;
-    hipStream_t cur_stream = nullptr;   // the caller's stream of the call in progress (profiling: tells critical-chain launches from side-stream ones)
+    hipStream_t cur_stream = nullptr; bool cur_stream_set = false;   // the caller's stream of the call in progress (profiling: tells critical-chain launches from side-stream ones)
 };
 
 // RAII: brackets the launches of one logical kernel with events when profiling is on.
@@ -95,7 +95,7 @@ struct ProfScope {
     ProfScope(vae_ctx* c_, const char* name, double bytes, double flops, hipStream_t st_) : c(c_), st(st_), idx(-1) {
         if (!c || !c->prof) return;
         vae_ctx::ProfRec r; r.name = std::string(name) + (c->tag ? std::string(" @") + c->tag : std::string()); r.bytes = bytes; r.flops = flops;
-        r.side = (c->cur_stream && st != c->cur_stream) ? 1 : 0;
+        r.side = (c->cur_stream_set && st != c->cur_stream) ? 1 : 0;   // (the legacy default stream is the null handle)
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
         (void)hipEventRecord(r.e0, st);
         c->prof_recs.push_back(r); idx = (int)c->prof_recs.size() - 1;
