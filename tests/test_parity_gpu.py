@@ -938,3 +938,34 @@ def test_library_allreduce_single_rank_rccl():
     offs = (C.c_int64 * 1)(0); sizes = (C.c_int64 * 1)(16)
     assert _lib.lib().vae_allreduce_grads(m._ctx.handle, m.flat_grads().data_ptr(), 1, offs, sizes, 1, torch.cuda.current_stream().cuda_stream) != 0
     assert b"no communicator" in _lib.lib().vae_last_error()
+
+
+@pytest.mark.parametrize("cfg", [(64, 16, 5, "bf16"), (128, 16, 3, "f16"), (32, 16, 9, "bf16"), (64, 64, 2, "f16")])
+def test_fused_dgrad_wgrad_matches_separate_kernels(cfg):
+    """conv_fused.cuh (one pass over (dz, y) for the input AND the weight gradient of final_layer.0 / decoder.2) against the
+    separate input-gradient and weight-gradient kernels.  Same operands and the same MFMA accumulation order for the input
+    gradient, so the dz it writes is bit-identical; the weight gradient and the BatchNorm statistics are summed in a different
+    order (rounding level); everything downstream sees those last-bit differences through 16-bit roundings."""
+    from torch_vae_amd import _lib
+    H, L, B, dtype = cfg
+    p = perturbed_params(L, H, 14, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 19)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 19, 5).reshape(B, L)).float().cuda()
+    res = []
+    for use in (0, 1):
+        model = make_model(H, L, True, dtype, p)
+        model._context(B)
+        assert _lib.lib().vae_set_option(model._ctx.handle, b"use_fused_wgrad", use) == 0
+        out3, _ = model.fused_forward_backward(x, eps=eps)
+        n = B * 32 * (H // 2) ** 2
+        dz6 = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(model._ctx.handle, 8 + 6, dz6.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        res.append((out3.cpu().numpy(), dz6.cpu().numpy(), flat_grad_dict(model)))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])                       # dz of decoder.2's output, written by the layer-7 kernel
+    g0, g1 = res[0][2], res[1][2]
+    for n in ("final_layer.0.weight", "final_layer.1.weight", "final_layer.1.bias", "final_layer.3.weight", "decoder.2.1.weight", "decoder.2.1.bias"):
+        assert rel_l2(g1[n], g0[n]) < 2e-5, (n, rel_l2(g1[n], g0[n]))
+    for n in g0:
+        if n not in PRE_BN_BIAS:
+            assert rel_l2(g1[n], g0[n]) < (2e-2 if dtype == "bf16" else 5e-3), (n, rel_l2(g1[n], g0[n]))

@@ -1,0 +1,301 @@
+// Fused backward of a ConvTranspose2d(k3,s2,p1,op1) layer whose high-resolution side has 32 channels (final_layer.0:
+// 32->32, decoder.2: 64->32 of the reference, models.py:62-77): ONE pass over the layer's (dz, y) pair produces both
+//   the input gradient   dz_prev[b,iy,ix,ci] = leaky'(z_prev) * sum_{ky,kx,co} g[b,2iy+ky-1,2ix+kx-1,co] * Wt[ci][co][ky][kx]
+//   the weight gradient  dWt[ci][co][ky][kx]  = sum_{b,iy,ix} a_prev[b,iy,ix,ci] * g[b,2iy+ky-1,2ix+kx-1,co]
+// where g = p0*dz + p1*y + p2 is the BatchNorm backward of this layer (applied while the patch is staged, never
+// materialised) and a_prev = LeakyReLU(BN(y_prev)).  The separate kernels (down2_kernel + wgrad_kernel) each stream the
+// (dz, y) pair - for final_layer.0 at the benchmark workload that is 2 x 536 MB of the step's 4.5 GB of kernel traffic;
+// here it is read once.  These two layers are HBM-bound (32-channel tensors at the two largest resolutions); the deeper
+// layers are MFMA-bound, their weight gradients are too large to live in registers, and they keep the separate kernels.
+//
+// Workgroup = 8 waves on an 8 x 16 low-res pixel tile of one image (patch 17 x 33 high-res pixels), persistent over tiles:
+//   all waves   : next tile's raw (dz, y) chunks and y_prev rows prefetched in registers (5 + 5 + CLO/32 vectors per
+//                 thread), transformed into the LDS patch after the barrier that retires the previous tile;
+//                 weight gradient: the 9 taps (x low-res channel blocks) are split over the 8 waves, K = the tile's 128
+//                 pixels read k-major from LDS (ds_read_b64_tr_b16), accumulators (2-3 tiles per wave) live in registers
+//                 across all tiles of the workgroup and are written once, as one split-K slab per workgroup
+//                 (reduce_slab_kernel sums them)
+//   waves 0..3  : also the input gradient of 32 pixels each (18 MFMA per 32 output channels, weights from an LDS image
+//                 loaded once per workgroup), epilogue (LeakyReLU', BatchNorm statistics of the previous layer) in place
+//                 over the wave's own rows of the y_prev tile, 16-byte coalesced stores
+// Splitting the weight-gradient tiles over all waves keeps every wave under 256 registers (two waves per SIMD).
+#pragma once
+#include "conv_mfma.cuh"
+#include "conv_pipe.cuh"
+
+template <typename T> struct ConvTFusedArgs {
+    const T* dz; const T* y;            // this layer (high-res side) [B, 2Hs, 2Ws, 32]
+    const float* gcoef;                 // rows p0,p1,p2 (stride 32) when fuse.mode == BNF_NONE
+    BnFuse fuse;                        // BNF_BWD: derive p0..p2 from the batch statistics here (workgroup 0 records them)
+    const T* wp;                        // packed dgrad weights [9][32/8][CLO][8]
+    const T* yprev; const float* ocoef; // previous layer (low-res side) [B, Hs, Ws, CLO]; its block rows LC_* (stride CLO)
+    T* dzprev; double* stat;            // outputs: dz of the previous layer, [sum dz | sum dz*xhat] (replicated, 2*CLO)
+    float* slab;                        // [gridDim.x][9][CLO][32] partial weight gradients
+    float slope;
+    int B, Hs, Ws, n_tiles, tiles_x, tiles_y, rev;
+};
+
+template <typename T, int CLO>
+__global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<T> a) {
+    static_assert(sizeof(T) == 2, "16-bit storage only (f32 keeps the separate kernels)");
+    static_assert(CLO == 32 || CLO == 64, "low-res channel count");
+    typedef typename H16<T>::v8 T8;
+    constexpr int TH = 8, TW = 16, NPX = TH * TW, PH = 2 * TH + 1, PW = 2 * TW + 1, NP = PH * PW;   // 128 px, 17 x 33 patch
+    constexpr int NCHK = NP * 4, MAXI = (NCHK + 511) / 512;                                          // 2244 chunks, 5 per thread
+    constexpr int GP = 80;                                   // patch pitch: 64 B of channels + 16 B pad
+    constexpr int NB = CLO / 32;                             // 32-channel blocks of the low-res side
+    constexpr int AP = CLO * 2 + 16;                         // y_prev / dz_prev tile pitch
+    constexpr int ACH = CLO * 2 / 16, NYC = NPX * ACH / 512; // 16-byte chunks per low-res pixel; y_prev chunks per thread
+    constexpr int NWT = (9 * NB + 7) / 8;                    // weight-gradient accumulator tiles per wave (tile idx = wave + 8j)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gpatch = smem;                                     // [NP][GP]   g = BN-backward(dz, y), storage type
+    char* atile = gpatch + NP * GP;                          // [NPX][AP]  a_prev = LeakyReLU(BN(y_prev)): the weight gradient's A operand
+    char* ytile = atile + NPX * AP;                          // [NPX][AP]  raw y_prev, overwritten in place by dz_prev (rows of a dgrad wave are private to it)
+    char* wlds = ytile + NPX * AP;                           // [9][4][CLO][8] dgrad weights
+    float* cf = reinterpret_cast<float*>(wlds + 9 * 4 * CLO * 16);   // [3][32] p0,p1,p2 of this layer
+    float* cfp = cf + 96;                                    // [2][CLO] scale, shift of the previous layer's BatchNorm
+    float* red = cfp + 2 * CLO;                              // [4 waves][CLO][2]
+    int2* gtab = reinterpret_cast<int2*>(red + 4 * CLO * 2); // [MAXI*512] tile-independent chunk geometry (kept out of the registers)
+    char* dummy = reinterpret_cast<char*>(gtab + MAXI * 512); // 16 bytes: where the (masked) chunks beyond the patch are stored
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int Hg = 2 * a.Hs, Wg = 2 * a.Ws;
+
+    // ---- prologue: coefficients, weights, tile-independent chunk geometry
+    if (tid < 32) {
+        if (a.fuse.mode == BNF_BWD) bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], cf[32 + tid], cf[64 + tid]);
+        else { cf[tid] = a.gcoef[tid]; cf[32 + tid] = a.gcoef[32 + tid]; cf[64 + tid] = a.gcoef[64 + tid]; }
+    }
+    if (tid >= 64 && tid < 64 + CLO) { const int n = tid - 64; cfp[n] = a.ocoef[LC_SC * CLO + n]; cfp[CLO + n] = a.ocoef[LC_SH * CLO + n]; }
+    for (int i = tid; i < 9 * 4 * CLO; i += 512)
+        *reinterpret_cast<T8*>(wlds + i * 16) = *reinterpret_cast<const T8*>(reinterpret_cast<const char*>(a.wp) + (size_t)i * 16);
+    // chunk u of a thread: id = tid + 512u -> patch pixel id>>2, channel quarter id&3 = tid&3 (the same for every u).
+    // Table entry: {element offset relative to the patch origin, LDS offset | top<<20 | left<<21 | beyond<<22}
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        const int id = tid + 512 * u, pix = id >> 2, py = pix / PW, px = pix - py * PW;
+        gtab[id] = make_int2((py * Wg + px) * 32 + (id & 3) * 8,
+                             (id < NCHK ? pix * GP + (id & 3) * 16 : (int)(dummy - gpatch)) | ((py == 0) << 20) | ((px == 0) << 21) | ((id >= NCHK) << 22));
+    }
+    __syncthreads();
+
+    auto tile_origin = [&](int t_, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        const int t = a.rev ? a.n_tiles - 1 - t_ : t_;   // reversed walk: start with what the producer wrote last
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y;
+        b = t / (a.tiles_x * a.tiles_y); y0 = ty * TH; x0 = tx * TW;
+    };
+    // prefetch registers (raw vectors)
+    T8 pz[MAXI], py_[MAXI], pyp[NYC];
+    int pok = 0;   // validity bits of the prefetched chunks
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        int b, y0, x0; tile_origin(t, b, y0, x0);
+        const int base = ((b * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * 32;
+        const int tmask = (y0 == 0 ? 1 << 20 : 0) | (x0 == 0 ? 1 << 21 : 0) | (1 << 22);
+        pok = 0;
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int2 e = gtab[tid + 512 * u];
+            const bool ok = (e.y & tmask) == 0;
+            pok |= ok ? (1 << u) : 0;
+            const uint32_t off = ok ? (uint32_t)(base + e.x) * 2u : 0u;
+            pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
+            py_[u] = *reinterpret_cast<const T8*>(at_bytes(a.y, off));
+        }
+#pragma unroll
+        for (int u = 0; u < NYC; ++u) {
+            const int id = tid + 512 * u, R = id / ACH, qq = id - R * ACH;
+            const uint32_t off = (uint32_t)(((b * a.Hs + y0 + (R >> 4)) * a.Ws + x0 + (R & 15)) * CLO + qq * 8) * 2u;
+            pyp[u] = *reinterpret_cast<const T8*>(at_bytes(a.yprev, off));
+        }
+    };
+
+    // ---- per-role state (all waves: weight-gradient tiles wave + 8j; waves 0..3 also the input gradient of 32 pixel rows)
+    const int wq = wave & 3;
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;          // lane geometry of the transposed LDS reads
+    const int Rr = wq * 32 + r, pbase = (2 * (Rr >> 4)) * PW + 2 * (Rr & 15);   // dgrad: this lane's pixel row -> patch pixel of tap (0,0)
+    float esc[NB], esh[NB], eis[NB], exm[NB];   // previous layer's forward coefficients of channel nb*32 + r
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 32 + r;
+        esc[nb] = a.ocoef[LC_SC * CLO + n]; esh[nb] = a.ocoef[LC_SH * CLO + n];
+        eis[nb] = a.ocoef[LC_INVSTD * CLO + n]; exm[nb] = a.ocoef[LC_XM * CLO + n];
+    }
+    // weight-gradient tiles of this wave: idx = wave + 8j < 9*NB -> tap idx / NB, low-res channel block idx % NB (= wave % NB)
+    const bool cib1 = NB == 2 && (wave & 1);
+    const int acol = ((cib1 ? 32 : 0) + 16 * (g4 & 1) + 4 * p) * 2, bcol = (16 * (g4 & 1) + 4 * p) * 2;
+    f32x16 wacc[NWT];
+#pragma unroll
+    for (int j = 0; j < NWT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wacc[j][i] = 0.f;
+    f32x2 s1[NB], s2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { s1[nb] = f32x2{0.f, 0.f}; s2[nb] = f32x2{0.f, 0.f}; }
+
+    // g = p0*dz + p1*y + p2 on packed pairs; the thread's 8 channels of p0,p1,p2 are re-read from LDS per tile, so
+    // that they are not live across the matrix phase
+    auto xform = [&](const T8& vz, const T8& vy, const f32x2* k0, const f32x2* k1, const f32x2* k2) __attribute__((always_inline)) {
+        T8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 x0 = {(float)vz[2 * e], (float)vz[2 * e + 1]}, x1 = {(float)vy[2 * e], (float)vy[2 * e + 1]};
+            const f32x2 z = x0 * k0[e] + (x1 * k1[e] + k2[e]);
+            o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
+        }
+        return o;
+    };
+
+    int t = blockIdx.x;
+    if (t < a.n_tiles) issue(t);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int b, y0, x0; tile_origin(t, b, y0, x0);
+        __syncthreads();                                   // (A) previous tile fully consumed
+        // ---- stage this tile; as each register pair becomes free, request the same chunk of the next tile
+        const int tn = t + (int)gridDim.x;
+        const bool nh = tn < a.n_tiles;
+        int nb_ = b, ny0 = y0, nx0 = x0;
+        if (nh) tile_origin(tn, nb_, ny0, nx0);
+        const int nbase = ((nb_ * Hg + 2 * ny0 - 1) * Wg + 2 * nx0 - 1) * 32;
+        const int ntmask = (ny0 == 0 ? 1 << 20 : 0) | (nx0 == 0 ? 1 << 21 : 0) | (1 << 22);
+        int npok = 0;
+        f32x2 k0[4], k1[4], k2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid & 3) * 8 + 2 * e;
+            k0[e] = *reinterpret_cast<const f32x2*>(cf + c); k1[e] = *reinterpret_cast<const f32x2*>(cf + 32 + c); k2[e] = *reinterpret_cast<const f32x2*>(cf + 64 + c);
+        }
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int2 e = gtab[tid + 512 * u];
+            T8 o = xform(pz[u], py_[u], k0, k1, k2);
+            if (!((pok >> u) & 1)) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<T8*>(gpatch + (e.y & 0xfffff)) = o;   // (chunks beyond the patch land in the dummy slot)
+            const bool ok = nh & ((e.y & ntmask) == 0);
+            npok |= ok ? (1 << u) : 0;
+            const uint32_t off = ok ? (uint32_t)(nbase + e.x) * 2u : 0u;
+            pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
+            py_[u] = *reinterpret_cast<const T8*>(at_bytes(a.y, off));
+        }
+        pok = npok;
+#pragma unroll
+        for (int u = 0; u < NYC; ++u) {
+            const int id = tid + 512 * u, R = id / ACH, qq = id - R * ACH;
+            *reinterpret_cast<T8*>(ytile + R * AP + qq * 16) = pyp[u];
+            T8 av;   // a_prev for the weight gradient (the chunk's 8 channels: qq*8 ..)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 sc2 = *reinterpret_cast<const f32x2*>(cfp + qq * 8 + 2 * e), sh2 = *reinterpret_cast<const f32x2*>(cfp + CLO + qq * 8 + 2 * e);
+                f32x2 z = f32x2{(float)pyp[u][2 * e], (float)pyp[u][2 * e + 1]} * sc2 + sh2;
+                const f32x2 zs = z * a.slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+                av[2 * e] = (T)z.x; av[2 * e + 1] = (T)z.y;
+            }
+            *reinterpret_cast<T8*>(atile + R * AP + qq * 16) = av;
+            const uint32_t off = nh ? (uint32_t)(((nb_ * a.Hs + ny0 + (R >> 4)) * a.Ws + nx0 + (R & 15)) * CLO + qq * 8) * 2u : 0u;
+            pyp[u] = *reinterpret_cast<const T8*>(at_bytes(a.yprev, off));
+        }
+        __syncthreads();                                   // (B) patch and y_prev tile published
+
+        if (wave < 4) {
+            // ---- input gradient of pixel rows wq*32 .. wq*32+31
+            f32x16 dacc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dacc[nb][i] = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const Frag<T> af = load_frag(reinterpret_cast<const T*>(gpatch + (pbase + (tp / 3) * PW + (tp % 3)) * GP + ks * 32) + h * 8);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const Frag<T> bf = load_frag(reinterpret_cast<const T*>(wlds + (((tp * 4 + 2 * ks + h) * CLO + nb * 32 + r) * 16)));
+                        mma(dacc[nb], af, bf);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads of later taps from being hoisted (register budget)
+            }
+            // epilogue: dz_prev = leaky'(z_prev) * acc, statistics of the stored values; rows of this wave only
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const int R0 = wq * 32 + acc_row(i, lane), R1 = wq * 32 + acc_row(i + 1, lane), n = nb * 32 + r;
+                    T* c0 = reinterpret_cast<T*>(ytile + R0 * AP + n * 2); T* c1 = reinterpret_cast<T*>(ytile + R1 * AP + n * 2);
+                    const f32x2 yv = {tofloat(*c0), tofloat(*c1)};
+                    const f32x2 z = yv * esc[nb] + esh[nb];
+                    f32x2 g = {dacc[nb][i], dacc[nb][i + 1]};
+                    g.x = z.x > 0.f ? g.x : g.x * a.slope; g.y = z.y > 0.f ? g.y : g.y * a.slope;
+                    const f32x2 dzv = round_pair<T>(g, *c0, *c1);
+                    s1[nb] += dzv; s2[nb] += dzv * yv;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed (wave-private rows)
+#pragma unroll
+            for (int u = 0; u < ACH / 2; ++u) {
+                const int id = lane + 64 * u, row = id / ACH, qq = id - row * ACH, R = wq * 32 + row;
+                const T8 v = *reinterpret_cast<const T8*>(ytile + R * AP + qq * 16);
+                const uint32_t off = (uint32_t)(((b * a.Hs + y0 + (R >> 4)) * a.Ws + x0 + (R & 15)) * CLO + qq * 8) * 2u;
+                *reinterpret_cast<T8*>(at_bytes(a.dzprev, off)) = v;
+            }
+        }
+        {
+            // ---- weight gradient: K = the tile's 128 pixels, A = a_prev^T (k-major reads of the a_prev tile), B = g at the tap's
+            // patch pixels (k-major reads of the patch).  Fragments are re-read per tile: LDS has the bandwidth, registers do not.
+#pragma unroll
+            for (int j = 0; j < NWT; ++j) {
+                const int idx = wave + 8 * j;
+                if (idx < 9 * NB) {   // wave-uniform
+                    const int tp = idx / NB, toff = (tp / 3) * PW + (tp % 3);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int kk0 = ks * 16 + 8 * (g4 >> 1) + q, kk1 = kk0 + 4;
+                        const int gb0 = (2 * (kk0 >> 4)) * PW + 2 * (kk0 & 15), gb1 = (2 * (kk1 >> 4)) * PW + 2 * (kk1 & 15);
+                        const Frag<T> af = frag_tr16<T>(atile + kk0 * AP + acol, atile + kk1 * AP + acol);
+                        const Frag<T> bf = frag_tr16<T>(gpatch + (gb0 + toff) * GP + bcol, gpatch + (gb1 + toff) * GP + bcol);
+                        mma(wacc[j], af, bf);
+                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // at most two k-steps of fragments in flight
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- workgroup results: BatchNorm statistics of the previous layer (dgrad waves), weight-gradient slab (wgrad waves)
+    if (wave < 4) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float v1 = s1[nb].x + s1[nb].y, v2 = s2[nb].x + s2[nb].y;
+            v2 = eis[nb] * v2 + exm[nb] * v1;                    // sum dz*xhat from sum dz*y and sum dz
+            v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
+            if (h == 0) { red[((wq * NB + nb) * 32 + r) * 2] = v1; red[((wq * NB + nb) * 32 + r) * 2 + 1] = v2; }
+        }
+    }
+    {
+#pragma unroll
+        for (int j = 0; j < NWT; ++j) {
+            const int idx = wave + 8 * j;
+            if (idx < 9 * NB) {
+                const int tp = idx / NB, cib = idx % NB;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    a.slab[(((size_t)blockIdx.x * 9 + tp) * CLO + cib * 32 + acc_row(i, lane)) * 32 + r] = wacc[j][i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < CLO) {
+        const int nb = tid >> 5, c = tid & 31;
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v1 += red[((w * NB + nb) * 32 + c) * 2]; v2 += red[((w * NB + nb) * 32 + c) * 2 + 1]; }
+        double* st_ = a.stat + stat_rep() * 2 * CLO;
+        unsafeAtomicAdd(&st_[tid], (double)v1);
+        unsafeAtomicAdd(&st_[CLO + tid], (double)v2);
+    }
+}
+
+// LDS bytes of convt_bwd_fused_kernel<T, CLO>
+static inline size_t convt_fused_lds(int CLO) {
+    return (size_t)(17 * 33) * 80 + 2 * (size_t)128 * (CLO * 2 + 16) + (size_t)9 * 4 * CLO * 16 + 96 * 4 + (size_t)2 * CLO * 4 + (size_t)4 * CLO * 2 * 4 + (size_t)5 * 512 * 8 + 16;
+}

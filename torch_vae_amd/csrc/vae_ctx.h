@@ -76,6 +76,8 @@ struct vae_ctx {
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     double* generic_accum;                           // vae_elbo_generic on this context's device (per context, not process-global)
     WgradKnobs wk;
+    float* fused_slab[2] = {nullptr, nullptr}; size_t fused_slab_floats = 0;   // split-K slabs of the fused dgrad+wgrad kernels (layers 7, 6)
+    int use_fused_wgrad = 1, knob_fused_grid = 256;
     // f16 storage: the backward runs on gradients multiplied by gmul (a power of two chosen per forward so that the stored
     // dz stay inside the f16 range: the BCE mean makes them O(1/(B*H*W))); every parameter gradient is written times ginv.
     // The backward is linear in the upstream gradient, so this changes no f32 result (powers of two are exact).  1 otherwise.

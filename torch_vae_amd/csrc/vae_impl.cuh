@@ -5,6 +5,7 @@
 #include "conv_mfma.cuh"
 #include "conv_pipe.cuh"
 #include "edge_kernels.cuh"
+#include "conv_fused.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -405,6 +406,45 @@ int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* 
 }
 
 
+// Fused input + weight gradient of a ConvTranspose2d layer with a 32-channel high-res side (conv_fused.cuh): layers 7
+// (final_layer.0) and 6 (decoder.2).  Returns 1 when the shape / storage type is outside the fused kernel's domain (the
+// caller then takes the separate kernels), 0 on success, -1 on error.
+template <typename T>
+static int launch_convt_fused(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return 1;
+    else {
+        const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
+        const int Hs = l.H / 2, Ws = l.W / 2, CLO = lp.C;
+        if (!c->use_fused_wgrad || !c->use_pipelined || !c->use_fused_bn || l.C != 32 || (CLO != 32 && CLO != 64) || Hs % 8 || Ws % 16) return 1;
+        if (4.0 * c->B * Hs * Ws * 32 * sizeof(T) >= 4294967296.0 || 1.0 * c->B * Hs * Ws * CLO * sizeof(T) >= 4294967296.0) return 1;   // 32-bit byte offsets
+        const int fs = i == 7 ? 0 : 1;
+        ConvTFusedArgs<T> a; memset(&a, 0, sizeof(a));
+        a.dz = reinterpret_cast<const T*>(l.dz); a.y = reinterpret_cast<const T*>(l.y); a.gcoef = l.block + LC_P0 * l.C;
+        a.fuse = make_fuse_bwd(c, i, params, grads);
+        a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
+        a.yprev = reinterpret_cast<const T*>(lp.y); a.ocoef = lp.block; a.dzprev = reinterpret_cast<T*>(lp.dz); a.stat = lp.stat_b;
+        a.slab = c->fused_slab[fs]; a.slope = kSlope;
+        a.B = c->B; a.Hs = Hs; a.Ws = Ws; a.tiles_x = Ws / 16; a.tiles_y = Hs / 8; a.n_tiles = c->B * a.tiles_x * a.tiles_y;
+        a.rev = (c->knob_rev >> 2) & 1;
+        const int grid = std::min(a.n_tiles, c->knob_fused_grid);
+        if ((size_t)grid * 9 * CLO * 32 > c->fused_slab_floats) return 1;
+        const size_t lds = convt_fused_lds(CLO);
+        const double px = (double)c->B * Hs * Ws;
+        {
+            ProfScope ps(c, "convT_bwd_fused(dgrad+wgrad)", sizeof(T) * (2.0 * 4 * px * 32 + 2.0 * px * CLO + 9.0 * 32 * CLO) + 4.0 * 9 * 32 * CLO,
+                         2.0 * 2 * 9 * 32 * CLO * px, st);
+            if (CLO == 32) { if (set_lds(convt_bwd_fused_kernel<T, 32>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 32>), dim3(grid), dim3(512), lds, st, a); }
+            else { if (set_lds(convt_bwd_fused_kernel<T, 64>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 64>), dim3(grid), dim3(512), lds, st, a); }
+            LAUNCH_CHECK("convt_bwd_fused_kernel");
+        }
+        // the per-workgroup slabs are summed beside the chain (the buffer is this layer's own: next written in the next step)
+        SideFork f = fork_side(c, st);
+        if (f.rc) return -1;
+        if (launch_reduce(a.slab, grid, (size_t)9 * CLO * 32, grads + c->poff[l.p_convw], CLO, 32, f.st, c)) return -1;
+        return 0;
+    }
+}
+
 template <typename T>
 static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t st) {
     SideFork f = fork_side(c, st);
@@ -472,6 +512,11 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
     for (int i = 7; i >= 4; --i) {
         c->tag = kLayerTag[i];
+        if (i >= 6) {   // 32-channel high-res side: one pass over (dz, y) for both gradients
+            const int rc = launch_convt_fused<T>(c, i, params, grads, st);
+            if (rc < 0) return -1;
+            if (rc == 0) continue;
+        }
         const BnLayer& l = c->lay[i];
         const int Cin = i == 4 ? 256 : c->lay[i - 1].C;
         WgradArgs<T> w; memset(&w, 0, sizeof(w));
