@@ -248,7 +248,10 @@ def main():
     else:
         if args.dump_order and seq is not None:
             json.dump(seq[:len(seq) // nprof], open(args.dump_order, "w"))
-        dom = next((k for k in kernels if k["bytes"] > 0), kernels[0])   # (skip zero-byte bookkeeping launches)
+        # dominant = most total time among the launches that move real data (>= 10 % of the largest per-launch byte count):
+        # bookkeeping launches (reductions of a few KB, finalisations) can take long when ranks share a GPU, yet say nothing
+        bmax = max(k["bytes"] / k["calls"] for k in kernels)
+        dom = next((k for k in kernels if k["bytes"] / k["calls"] >= 0.1 * bmax), kernels[0])
         ach = dom["gbs"]
         # algorithmic bytes of every launch overlapping the dominant launch's windows / total window time
         wbytes, wtime, mates = 0.0, 0.0, set()

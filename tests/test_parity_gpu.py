@@ -952,20 +952,23 @@ def test_fused_dgrad_wgrad_matches_separate_kernels(cfg):
     x = torch.from_numpy(vo.synth_pianoroll(B, H, 19)).cuda()
     eps = torch.from_numpy(vo.counter_normal(B * L, 19, 5).reshape(B, L)).float().cuda()
     res = []
-    for use in (0, 1):
+    # separate kernels; fused with the stored dz; fused with final_layer.0's dz recomputed from dlogit (never stored)
+    for use, recomp in ((0, 0), (1, 0), (1, 1)):
         model = make_model(H, L, True, dtype, p)
         model._context(B)
         assert _lib.lib().vae_set_option(model._ctx.handle, b"use_fused_wgrad", use) == 0
+        assert _lib.lib().vae_set_option(model._ctx.handle, b"use_recomp_dz", recomp) == 0
         out3, _ = model.fused_forward_backward(x, eps=eps)
         n = B * 32 * (H // 2) ** 2
         dz6 = torch.empty(n, device="cuda")
         _lib.check(_lib.lib().vae_debug_tensor(model._ctx.handle, 8 + 6, dz6.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
         res.append((out3.cpu().numpy(), dz6.cpu().numpy(), flat_grad_dict(model)))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])                       # dz of decoder.2's output, written by the layer-7 kernel
-    g0, g1 = res[0][2], res[1][2]
-    for n in ("final_layer.0.weight", "final_layer.1.weight", "final_layer.1.bias", "final_layer.3.weight", "decoder.2.1.weight", "decoder.2.1.bias"):
-        assert rel_l2(g1[n], g0[n]) < 2e-5, (n, rel_l2(g1[n], g0[n]))
-    for n in g0:
-        if n not in PRE_BN_BIAS:
-            assert rel_l2(g1[n], g0[n]) < (2e-2 if dtype == "bf16" else 5e-3), (n, rel_l2(g1[n], g0[n]))
+    for k in (1, 2):
+        np.testing.assert_array_equal(res[0][0], res[k][0])
+        np.testing.assert_array_equal(res[0][1], res[k][1])                   # dz of decoder.2's output, written by the layer-7 kernel
+        g0, g1 = res[0][2], res[k][2]
+        for n in ("final_layer.0.weight", "final_layer.1.weight", "final_layer.1.bias", "final_layer.3.weight", "decoder.2.1.weight", "decoder.2.1.bias"):
+            assert rel_l2(g1[n], g0[n]) < 2e-5, (k, n, rel_l2(g1[n], g0[n]))
+        for n in g0:
+            if n not in PRE_BN_BIAS:
+                assert rel_l2(g1[n], g0[n]) < (2e-2 if dtype == "bf16" else 5e-3), (k, n, rel_l2(g1[n], g0[n]))

@@ -33,9 +33,16 @@ template <typename T> struct ConvTFusedArgs {
     float* slab;                        // [gridDim.x][9][CLO][32] partial weight gradients
     float slope;
     int B, Hs, Ws, n_tiles, tiles_x, tiles_y, rev;
+    // RECOMP (final_layer.0 only): dz of this layer is NOT read - it is recomputed per patch pixel from the output conv's
+    // logit gradient: dz[p][c] = leaky'(z[p][c]) * sum_t dlogit[p - off(t)] * wout[t][c]  (what convout_bwd_mfma_kernel
+    // would have stored, rounded the same way), so the 32-channel gradient tensor at full resolution never exists in HBM.
+    const float* dlogit; const float* gscale; float gmul;   // [B, 2Hs, 2Ws] f32; optional device scale; f16 gradient scale
+    const float* wout;                  // output-conv weights, tap-major [9][32] f32
+    const float* fcoef;                 // this layer's forward block (rows LC_SC / LC_SH, stride 32): z = sc*y + sh
 };
 
-template <typename T, int CLO>
+// RECOMP = false: g = BN-backward(dz, y) from the stored pair.  RECOMP = true (CLO = 32): dz recomputed from dlogit.
+template <typename T, int CLO, bool RECOMP = false>
 __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<T> a) {
     static_assert(sizeof(T) == 2, "16-bit storage only (f32 keeps the separate kernels)");
     static_assert(CLO == 32 || CLO == 64, "low-res channel count");
@@ -57,6 +64,12 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
     float* red = cfp + 2 * CLO;                              // [4 waves][CLO][2]
     int2* gtab = reinterpret_cast<int2*>(red + 4 * CLO * 2); // [MAXI*512] tile-independent chunk geometry (kept out of the registers)
     char* dummy = reinterpret_cast<char*>(gtab + MAXI * 512); // 16 bytes: where the (masked) chunks beyond the patch are stored
+    // RECOMP only: raw y patch (the chunks are staged untouched; the BatchNorm backward is applied per accumulator element
+    // after the dz product) and the (PH+2) x (PW+2) patch of dlogit
+    constexpr int DH = PH + 2, DW = PW + 2, NDL = DH * DW, NDLT = (NDL + 511) / 512;
+    char* rawy = dummy + 16;                                 // [NP + pad to 18*32][GP]
+    float* dlp = reinterpret_cast<float*>(rawy + 18 * 32 * GP);   // [DH][DW]
+    float* cf7 = dlp + ((NDL + 3) & ~3);                     // [2][32] sc, sh of this layer's forward BatchNorm
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int Hg = 2 * a.Hs, Wg = 2 * a.Ws;
 
@@ -66,6 +79,10 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
         else { cf[tid] = a.gcoef[tid]; cf[32 + tid] = a.gcoef[32 + tid]; cf[64 + tid] = a.gcoef[64 + tid]; }
     }
     if (tid >= 64 && tid < 64 + CLO) { const int n = tid - 64; cfp[n] = a.ocoef[LC_SC * CLO + n]; cfp[CLO + n] = a.ocoef[LC_SH * CLO + n]; }
+    if constexpr (RECOMP) {
+        if (tid >= 128 && tid < 160) { const int n = tid - 128; cf7[n] = a.fcoef[LC_SC * 32 + n]; cf7[32 + n] = a.fcoef[LC_SH * 32 + n]; }
+        for (int i = tid; i < (18 * 32 - NP) * GP / 16; i += 512) *reinterpret_cast<f32x4*>(rawy + NP * GP + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int i = tid; i < 9 * 4 * CLO; i += 512)
         *reinterpret_cast<T8*>(wlds + i * 16) = *reinterpret_cast<const T8*>(reinterpret_cast<const char*>(a.wp) + (size_t)i * 16);
     // chunk u of a thread: id = tid + 512u -> patch pixel id>>2, channel quarter id&3 = tid&3 (the same for every u).
@@ -84,8 +101,19 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
         b = t / (a.tiles_x * a.tiles_y); y0 = ty * TH; x0 = tx * TW;
     };
     // prefetch registers (raw vectors)
-    T8 pz[MAXI], py_[MAXI], pyp[NYC];
+    T8 pz[RECOMP ? 1 : MAXI], py_[MAXI], pyp[NYC];
+    float pdl[RECOMP ? NDLT : 1];
+    const float gs = RECOMP ? (a.gscale ? a.gscale[0] : 1.f) * a.gmul : 1.f;
     int pok = 0;   // validity bits of the prefetched chunks
+    auto issue_dl = [&](int b, int y0, int x0, bool have) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < (RECOMP ? NDLT : 0); ++u) {
+            const int i = tid + 512 * u, rr = i / DW, cc = i - rr * DW, gy = 2 * y0 - 2 + rr, gx = 2 * x0 - 2 + cc;
+            const bool in = have && i < NDL && gy >= 0 && gy < Hg && gx >= 0 && gx < Wg;
+            const float v = a.dlogit[in ? ((size_t)b * Hg + gy) * Wg + gx : 0];
+            pdl[u] = in ? v * gs : 0.f;
+        }
+    };
     auto issue = [&](int t) __attribute__((always_inline)) {
         int b, y0, x0; tile_origin(t, b, y0, x0);
         const int base = ((b * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * 32;
@@ -97,9 +125,10 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
             const bool ok = (e.y & tmask) == 0;
             pok |= ok ? (1 << u) : 0;
             const uint32_t off = ok ? (uint32_t)(base + e.x) * 2u : 0u;
-            pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
+            if constexpr (!RECOMP) pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
             py_[u] = *reinterpret_cast<const T8*>(at_bytes(a.y, off));
         }
+        issue_dl(b, y0, x0, true);
 #pragma unroll
         for (int u = 0; u < NYC; ++u) {
             const int id = tid + 512 * u, R = id / ACH, qq = id - R * ACH;
@@ -163,19 +192,32 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
             const int c = (tid & 3) * 8 + 2 * e;
             k0[e] = *reinterpret_cast<const f32x2*>(cf + c); k1[e] = *reinterpret_cast<const f32x2*>(cf + 32 + c); k2[e] = *reinterpret_cast<const f32x2*>(cf + 64 + c);
         }
+        const int cur_pok = pok;
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
             const int2 e = gtab[tid + 512 * u];
-            T8 o = xform(pz[u], py_[u], k0, k1, k2);
-            if (!((pok >> u) & 1)) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<T8*>(gpatch + (e.y & 0xfffff)) = o;   // (chunks beyond the patch land in the dummy slot)
+            if constexpr (RECOMP) {
+                // raw y (zeros outside the image): rawy shares the patch geometry; chunks beyond the patch go to the dummy slot
+                T8 o = py_[u];
+                if (!((pok >> u) & 1)) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<T8*>(((e.y >> 22) & 1 ? gpatch : rawy) + (e.y & 0xfffff)) = o;
+            } else {
+                T8 o = xform(pz[u], py_[u], k0, k1, k2);
+                if (!((pok >> u) & 1)) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<T8*>(gpatch + (e.y & 0xfffff)) = o;   // (chunks beyond the patch land in the dummy slot)
+            }
             const bool ok = nh & ((e.y & ntmask) == 0);
             npok |= ok ? (1 << u) : 0;
             const uint32_t off = ok ? (uint32_t)(nbase + e.x) * 2u : 0u;
-            pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
+            if constexpr (!RECOMP) pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
             py_[u] = *reinterpret_cast<const T8*>(at_bytes(a.y, off));
         }
         pok = npok;
+        if constexpr (RECOMP) {
+#pragma unroll
+            for (int u = 0; u < NDLT; ++u) { const int i = tid + 512 * u; if (i < NDL) dlp[i] = pdl[u]; }
+            issue_dl(nb_, ny0, nx0, nh);
+        }
 #pragma unroll
         for (int u = 0; u < NYC; ++u) {
             const int id = tid + 512 * u, R = id / ACH, qq = id - R * ACH;
@@ -193,7 +235,54 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
             const uint32_t off = nh ? (uint32_t)(((nb_ * a.Hs + ny0 + (R >> 4)) * a.Ws + nx0 + (R & 15)) * CLO + qq * 8) * 2u : 0u;
             pyp[u] = *reinterpret_cast<const T8*>(at_bytes(a.yprev, off));
         }
-        __syncthreads();                                   // (B) patch and y_prev tile published
+        __syncthreads();                                   // (B) patch (RECOMP: raw y + dlogit) and y_prev tile published
+        if constexpr (RECOMP) {
+            // ---- dz of this layer for the 17 x 33 patch pixels: 18 blocks of 32 pixels over the 8 waves, ONE k-step each
+            // (K = 9 taps, padded to 16), the same product convout_bwd_mfma_kernel forms; then LeakyReLU', the storage
+            // rounding the stored tensor would have had, and the BatchNorm backward, per accumulator element
+            Frag<T> wfrag;   // B[k = tap][n = channel r]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int tp = 8 * h + j; wfrag.v[j] = (T)(tp < 9 ? a.wout[tp * 32 + r] : 0.f); }
+            const float sc7 = cf7[r], sh7 = cf7[32 + r], q0 = cf[r], q1 = cf[32 + r], q2 = cf[64 + r];
+            const bool top_out = y0 == 0, left_out = x0 == 0;
+#pragma unroll 1
+            for (int m = wave; m < 18; m += 8) {
+                const int pm = m * 32 + r, pmc = pm < NP ? pm : NP - 1, ppy = pmc / PW, ppx = pmc - ppy * PW;
+                Frag<T> af;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tp = 8 * h + j, tt = tp < 9 ? tp : 0;
+                    const float v = dlp[(ppy + 2 - tt / 3) * DW + (ppx + 2 - tt % 3)];
+                    af.v[j] = (T)(tp < 9 ? v : 0.f);
+                }
+                f32x16 da;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) da[i] = 0.f;
+                mma(da, af, wfrag);
+                // accumulator rows i, i+1 are consecutive patch pixels: processed as a pair so that the storage conversion is
+                // the packed instruction the staging transform of the stored-dz path uses (identical roundings, bit-identical g)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const int pe = m * 32 + acc_row(i, lane);     // (acc_row(i + 1) = acc_row(i) + 1; NP is odd, pe is even)
+                    if (pe < NP) {
+                        const bool two = pe + 1 < NP;
+                        const int ey0 = pe / PW, ex0 = pe - ey0 * PW, ey1 = (pe + 1) / PW, ex1 = pe + 1 - ey1 * PW;
+                        const f32x2 yv = {tofloat(*reinterpret_cast<const T*>(rawy + pe * GP + r * 2)), tofloat(*reinterpret_cast<const T*>(rawy + (pe + 1) * GP + r * 2))};
+                        const f32x2 z = yv * sc7 + sh7;
+                        f32x2 dzv = {tofloat(fromfloat<T>(z.x > 0.f ? da[i] : da[i] * a.slope)), tofloat(fromfloat<T>(z.y > 0.f ? da[i + 1] : da[i + 1] * a.slope))};
+                        f32x2 g = dzv * q0 + (yv * q1 + q2);
+                        if ((top_out && ey0 == 0) || (left_out && ex0 == 0)) g.x = 0.f;     // patch pixels outside the image carry no gradient
+                        if ((top_out && ey1 == 0) || (left_out && ex1 == 0)) g.y = 0.f;
+                        T o0, o1;
+                        (void)round_pair<T>(g, o0, o1);
+                        *reinterpret_cast<T*>(gpatch + pe * GP + r * 2) = o0;
+                        if (two) *reinterpret_cast<T*>(gpatch + (pe + 1) * GP + r * 2) = o1;
+                    }
+                }
+            }
+            (void)cur_pok;
+            __syncthreads();                               // (C) g patch published
+        }
 
         if (wave < 4) {
             // ---- input gradient of pixel rows wq*32 .. wq*32+31
@@ -295,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
     }
 }
 
-// LDS bytes of convt_bwd_fused_kernel<T, CLO>
-static inline size_t convt_fused_lds(int CLO) {
-    return (size_t)(17 * 33) * 80 + 2 * (size_t)128 * (CLO * 2 + 16) + (size_t)9 * 4 * CLO * 16 + 96 * 4 + (size_t)2 * CLO * 4 + (size_t)4 * CLO * 2 * 4 + (size_t)5 * 512 * 8 + 16;
+// LDS bytes of convt_bwd_fused_kernel<T, CLO, RECOMP>
+static inline size_t convt_fused_lds(int CLO, bool recomp = false) {
+    return (recomp ? (size_t)18 * 32 * 80 + (size_t)((19 * 35 + 3) & ~3) * 4 + 64 * 4 : 0) + (size_t)(17 * 33) * 80 + 2 * (size_t)128 * (CLO * 2 + 16) + (size_t)9 * 4 * CLO * 16 + 96 * 4 + (size_t)2 * CLO * 4 + (size_t)4 * CLO * 2 * 4 + (size_t)5 * 512 * 8 + 16;
 }

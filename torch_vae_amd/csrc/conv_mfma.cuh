@@ -642,10 +642,14 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
 // out[(a*CB+b)*9+t] = sum_s slab[s][t][a][b]   (CA>0: conv weight layout [A][B][3][3])
 // out[j]            = sum_s slab[s][j]          (CA==0)
 // block = 64 outputs x 4 slab groups; each thread keeps 8 independent loads in flight.
-static __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nslab, int n,
-                                                                 float* __restrict__ out, int CA, int CB, float scale) {
+// blockIdx.y = slab range [y*per, (y+1)*per) (per = nslab for a single-level reduction); a ranged launch writes its partial
+// sums to out + y*n (CA = 0 layout)
+static __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nslab_all, int n,
+                                                                 float* __restrict__ out, int CA, int CB, float scale, int per) {
     __shared__ float part[4][64];
     const int jl = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + jl;
+    slab += (size_t)blockIdx.y * per * n; out += (size_t)blockIdx.y * n;
+    const int nslab = min(per, nslab_all - (int)blockIdx.y * per);
     float s = 0.f;
     if (j < n) {
         int k = g;
@@ -811,6 +815,7 @@ template <typename T> struct ConvOutBwdMfmaArgs {
     T* dz; float* slab; double* stat; double* dbias;
     int B, H, W, n_tiles; float slope;
     int rev; float gmul;
+    int store_dz;   // 0: statistics / weight gradient only (the consumer recomputes dz from dlogit: conv_fused.cuh, RECOMP)
 };
 
 template <typename T>
@@ -932,12 +937,14 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
         }
         // the wave re-reads only its own 64 pixels (in-order LDS within a wave): 4 KiB = 4 chunks per lane
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.store_dz) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;
-            const T8 v = *reinterpret_cast<const T8*>(ytile + pix * PITCH + qq * 16);
-            const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
-            *reinterpret_cast<T8*>(a.dz + g) = v;
+            for (int u = 0; u < 4; ++u) {
+                const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;
+                const T8 v = *reinterpret_cast<const T8*>(ytile + pix * PITCH + qq * 16);
+                const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
+                *reinterpret_cast<T8*>(a.dz + g) = v;
+            }
         }
     }
 

@@ -147,6 +147,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
             c->n_side_ok = ok ? 1 : 0;
         }
     }
+    if (ok) { c->reduce_tmp_floats = 64 * 1024; c->reduce_tmp = dalloc<float>(c, c->reduce_tmp_floats); ok = c->reduce_tmp != nullptr; }
     if (ok && dtype != VAE_DTYPE_F32) {
         c->fused_slab_floats = (size_t)512 * 9 * 64 * 32;   // up to 512 workgroups x [9][64][32]
         for (int i = 0; i < 2 && ok; ++i) { c->fused_slab[i] = dalloc<float>(c, c->fused_slab_floats); ok = c->fused_slab[i] != nullptr; }
@@ -179,6 +180,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
     if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
     if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value; return 0; }
+    if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
     if (!strcmp(name, "knob_fused_grid")) { c->knob_fused_grid = std::max(1, std::min(value, 512)); return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { c->wk.tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { c->wk.wide = value; return 0; }

@@ -126,7 +126,20 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
 // (every caller reduces a parameter gradient: the result is written times c->ginv, the inverse of the f16 gradient scale)
 static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int CA, int CB, hipStream_t st, vae_ctx* c) {
     ProfScope ps(c, "reduce_slab", 4.0 * n * (nslab + 1), 0, st);
-    hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB, c->ginv);
+    // many slabs of a small tensor (the output conv's 288 weights from 1536 workgroups): a handful of workgroups summing
+    // them serially took 70-80 us; two levels: G partial sums per output, then the G partials
+    if (nslab >= 256 && n * 32 * 4 <= c->reduce_tmp_floats) {
+        const int G = 32, per = (nslab + G - 1) / G;
+        // (reductions on different streams may be in flight together: each takes the next of the buffer's slots)
+        const size_t nslots = c->reduce_tmp_floats / (n * G);
+        float* tmp = c->reduce_tmp + (size_t)(c->reduce_slot++ % nslots) * n * G;
+        hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64), G), dim3(256), 0, st, slab, nslab, (int)n, tmp, 0, 0, 1.f, per);
+        LAUNCH_CHECK("reduce_slab_kernel");
+        hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, tmp, G, (int)n, out, CA, CB, c->ginv, G);
+        LAUNCH_CHECK("reduce_slab_kernel");
+        return 0;
+    }
+    hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, nslab, (int)n, out, CA, CB, c->ginv, nslab);
     LAUNCH_CHECK("reduce_slab_kernel");
     return 0;
 }
@@ -410,30 +423,45 @@ int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* 
 // (final_layer.0) and 6 (decoder.2).  Returns 1 when the shape / storage type is outside the fused kernel's domain (the
 // caller then takes the separate kernels), 0 on success, -1 on error.
 template <typename T>
-static int launch_convt_fused(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
+static bool convt_fused_ok(vae_ctx* c, int i) {
+    if (sizeof(T) != 2) return false;
+    const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
+    const int Hs = l.H / 2, Ws = l.W / 2, CLO = lp.C;
+    if (!c->use_fused_wgrad || !c->use_pipelined || l.C != 32 || (CLO != 32 && CLO != 64) || Hs % 8 || Ws % 16) return false;
+    if (4.0 * c->B * Hs * Ws * 32 * sizeof(T) >= 4294967296.0 || 1.0 * c->B * Hs * Ws * CLO * sizeof(T) >= 4294967296.0) return false;   // 32-bit byte offsets
+    const int grid = std::min(c->B * (Ws / 16) * (Hs / 8), c->knob_fused_grid);
+    return (size_t)grid * 9 * CLO * 32 <= c->fused_slab_floats;
+}
+// recomp (layer 7 only): dz of the layer was not stored by the output-conv backward; it is recomputed from dl_src * dl_scale
+template <typename T>
+static int launch_convt_fused(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st, bool recomp = false,
+                              const float* dl_src = nullptr, const float* dl_scale = nullptr) {
     if constexpr (sizeof(T) != 2) return 1;
     else {
+        if (!convt_fused_ok<T>(c, i)) return 1;
         const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
         const int Hs = l.H / 2, Ws = l.W / 2, CLO = lp.C;
-        if (!c->use_fused_wgrad || !c->use_pipelined || !c->use_fused_bn || l.C != 32 || (CLO != 32 && CLO != 64) || Hs % 8 || Ws % 16) return 1;
-        if (4.0 * c->B * Hs * Ws * 32 * sizeof(T) >= 4294967296.0 || 1.0 * c->B * Hs * Ws * CLO * sizeof(T) >= 4294967296.0) return 1;   // 32-bit byte offsets
         const int fs = i == 7 ? 0 : 1;
         ConvTFusedArgs<T> a; memset(&a, 0, sizeof(a));
         a.dz = reinterpret_cast<const T*>(l.dz); a.y = reinterpret_cast<const T*>(l.y); a.gcoef = l.block + LC_P0 * l.C;
         a.fuse = make_fuse_bwd(c, i, params, grads);
+        if (!c->use_fused_bn) { if (bn_finalize_now(c, a.fuse, st)) return -1; a.fuse.mode = BNF_NONE; }   // standalone finalisation: coefficients from the block
         a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
         a.yprev = reinterpret_cast<const T*>(lp.y); a.ocoef = lp.block; a.dzprev = reinterpret_cast<T*>(lp.dz); a.stat = lp.stat_b;
         a.slab = c->fused_slab[fs]; a.slope = kSlope;
         a.B = c->B; a.Hs = Hs; a.Ws = Ws; a.tiles_x = Ws / 16; a.tiles_y = Hs / 8; a.n_tiles = c->B * a.tiles_x * a.tiles_y;
         a.rev = (c->knob_rev >> 2) & 1;
+        a.dlogit = dl_src; a.gscale = dl_scale; a.gmul = c->gmul; a.wout = c->wout_t; a.fcoef = l.block;
+        if (recomp && (CLO != 32 || !dl_src)) return vae_set_error("convt_fused", "recomputed dz: final_layer.0 only");
         const int grid = std::min(a.n_tiles, c->knob_fused_grid);
-        if ((size_t)grid * 9 * CLO * 32 > c->fused_slab_floats) return 1;
-        const size_t lds = convt_fused_lds(CLO);
+        const size_t lds = convt_fused_lds(CLO, recomp);
         const double px = (double)c->B * Hs * Ws;
         {
-            ProfScope ps(c, "convT_bwd_fused(dgrad+wgrad)", sizeof(T) * (2.0 * 4 * px * 32 + 2.0 * px * CLO + 9.0 * 32 * CLO) + 4.0 * 9 * 32 * CLO,
-                         2.0 * 2 * 9 * 32 * CLO * px, st);
-            if (CLO == 32) { if (set_lds(convt_bwd_fused_kernel<T, 32>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 32>), dim3(grid), dim3(512), lds, st, a); }
+            ProfScope ps(c, recomp ? "convT_bwd_fused(dz recomputed+dgrad+wgrad)" : "convT_bwd_fused(dgrad+wgrad)",
+                         sizeof(T) * ((recomp ? 1.0 : 2.0) * 4 * px * 32 + 2.0 * px * CLO + 9.0 * 32 * CLO) + 4.0 * 9 * 32 * CLO + (recomp ? 4.0 * 4 * px : 0.0),
+                         2.0 * 2 * 9 * 32 * CLO * px + (recomp ? 2.0 * 9 * 32 * 4 * px : 0.0), st);
+            if (recomp) { if (set_lds(convt_bwd_fused_kernel<T, 32, true>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 32, true>), dim3(grid), dim3(512), lds, st, a); }
+            else if (CLO == 32) { if (set_lds(convt_bwd_fused_kernel<T, 32>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 32>), dim3(grid), dim3(512), lds, st, a); }
             else { if (set_lds(convt_bwd_fused_kernel<T, 64>, lds)) return -1; hipLaunchKernelGGL((convt_bwd_fused_kernel<T, 64>), dim3(grid), dim3(512), lds, st, a); }
             LAUNCH_CHECK("convt_bwd_fused_kernel");
         }
@@ -478,6 +506,7 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
     // output conv backward + final_layer BN/LeakyReLU prologue
     c->tag = "final_layer.3";
     int cgrid = 0;
+    bool recomp7 = false;
     {
         ConvOutBwdArgs a;
         a.yf = c->lay[7].y; a.ocoef = c->lay[7].block; a.wt = c->wout_t; a.dlogit = dl_src; a.gscale = dl_scale;
@@ -485,11 +514,16 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         a.gmul = c->gmul;   // the gradient scale enters the backward here (and in latent_bwd / fc_dgrad for the other upstream gradients)
         const long P = (long)B * H * H;
         int grid = (int)std::min<long>((P + 63) / 64, 1024);
-        ProfScope ps(c, "convout_bwd(dgrad+wgrad+bn prologue)", ((double)sizeof(T) * 64 + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
+        const bool will_recomp = sizeof(T) == 2 && c->use_mfma_convout && c->use_recomp_dz && convt_fused_ok<T>(c, 7);
+        ProfScope ps(c, will_recomp ? "convout_bwd(statistics+wgrad, dz not stored)" : "convout_bwd(dgrad+wgrad+bn prologue)",
+                     ((double)sizeof(T) * (will_recomp ? 32 : 64) + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
         bool launched = false;
         if constexpr (sizeof(T) == 2) {
             if (c->use_mfma_convout) {
-                ConvOutBwdMfmaArgs<T> m; m.rev = (c->knob_rev >> 1) & 1;
+                // final_layer.0's gradient kernel can recompute dz from dlogit: then this pass only produces the statistics and
+                // the output conv's weight gradient, and the full-resolution 32-channel dz never goes to HBM
+                recomp7 = c->use_recomp_dz && convt_fused_ok<T>(c, 7);
+                ConvOutBwdMfmaArgs<T> m; m.rev = (c->knob_rev >> 1) & 1; m.store_dz = recomp7 ? 0 : 1;
                 m.yf = reinterpret_cast<const T*>(c->lay[7].y); m.ocoef = a.ocoef; m.wt = a.wt; m.dlogit = a.dlogit; m.gscale = a.gscale; m.gmul = a.gmul;
                 m.dz = reinterpret_cast<T*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat; m.dbias = a.dbias;
                 m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32); m.slope = kSlope;
@@ -513,7 +547,8 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
     for (int i = 7; i >= 4; --i) {
         c->tag = kLayerTag[i];
         if (i >= 6) {   // 32-channel high-res side: one pass over (dz, y) for both gradients
-            const int rc = launch_convt_fused<T>(c, i, params, grads, st);
+            const int rc = launch_convt_fused<T>(c, i, params, grads, st, i == 7 && recomp7, dl_src, dl_scale);
+            if (rc == 1 && i == 7 && recomp7) return vae_set_error("vae_backward", "dz of final_layer.0 was not stored");
             if (rc < 0) return -1;
             if (rc == 0) continue;
         }
