@@ -191,8 +191,9 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
  *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
  *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
- *   use_fused_wgrad [1]     one pass over (dz, y) for the input AND weight gradient of final_layer.0 / decoder.2 (16-bit storage;
- *                           conv_fused.cuh); knob_fused_grid [256] its persistent workgroups
+ *   use_fused_wgrad [1]     one pass over (dz, y) for the input AND weight gradient of final_layer.0 / decoder.2 / encoder.1
+ *                           (16-bit storage; conv_fused.cuh; 2: decoder side only, 3: encoder.1 only); knob_fused_grid [256] their
+ *                           persistent workgroups; use_recomp_dz [0] final_layer.0's dz recomputed from dlogit instead of stored
  *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
  *                           what its producer wrote last finds it in L2 / the memory-side cache

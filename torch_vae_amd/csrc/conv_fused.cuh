@@ -388,3 +388,325 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_fused_kernel(ConvTFusedArgs<
 static inline size_t convt_fused_lds(int CLO, bool recomp = false) {
     return (recomp ? (size_t)18 * 32 * 80 + (size_t)((19 * 35 + 3) & ~3) * 4 + 64 * 4 : 0) + (size_t)(17 * 33) * 80 + 2 * (size_t)128 * (CLO * 2 + 16) + (size_t)9 * 4 * CLO * 16 + 96 * 4 + (size_t)2 * CLO * 4 + (size_t)4 * CLO * 2 * 4 + (size_t)5 * 512 * 8 + 16;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward of a Conv2d(k3,s2,p1) layer with a 32-channel HIGH-res input side and 64 output channels (encoder.1 of the
+// reference: Conv2d(32, 64), models.py:41-51): one pass over the layer's (dz, y) pair (low-res) and the previous layer's y
+// (high-res) produces
+//   the input gradient   dz_prev[b, 2i+py, 2j+px, ci] = leaky'(z_prev) * sum_{taps of parity (py,px)} g[b, i+di, j+dj, co] * W[co][ci][t]
+//   the weight gradient  dW[co][ci][ky][kx] = sum_{b,oy,ox} g[b,oy,ox,co] * a_prev[b, 2oy+ky-1, 2ox+kx-1, ci]
+// with g = p0*dz + p1*y + p2 (BatchNorm backward of this layer) and a_prev = LeakyReLU(BN(y_prev)).  The separate kernels
+// (up2_kernel + wgrad_kernel) read y_prev and the (dz, y) pair twice; here once (+ the one-pixel halo of y_prev).
+//
+// Workgroup = 8 waves on an 8 x 8 low-res tile of one image = a 16 x 16 high-res output tile, persistent over tiles:
+//   all waves  : next tile's raw chunks prefetched in registers; staged after the barrier that retires the previous tile:
+//                g (9 x 9 low-res patch: the "up" taps reach one pixel right / down), a_prev (17 x 17 high-res patch with the
+//                top / left halo the weight gradient's taps need) and the raw y_prev rows of the output tile
+//   waves 0..3 : input gradient of 32 low-res pixels each (wave & 1) for one group of output parities (wave >> 1: the (odd,odd)
+//                class with its 4 taps, or the other three classes with 5 taps) - disjoint outputs, no cross-wave sum; the f32
+//                accumulators go to an LDS tile [pixel][channel]
+//   waves 2..7 : weight gradient, the 18 (tap, 32-channel block of co) tiles split 3 per wave (waves 2, 3 carry the light
+//                parity group of the input gradient as well), K = the tile's 64 low-res pixels read k-major
+//                (ds_read_b64_tr_b16); accumulators persist over the workgroup's tiles -> one slab per workgroup
+//   all waves  : after a barrier, the epilogue in CHUNK layout (a thread owns 8 channels of a pixel: packed math, every thread
+//                busy, instead of the accumulator layout's per-element 2-byte LDS cells on the four dgrad waves): LeakyReLU',
+//                storage rounding, BatchNorm statistics of the previous layer, 16-byte stores straight to HBM as 1-KiB rows
+template <typename T> struct ConvFusedArgs {
+    const T* dz; const T* y;            // this layer (low-res side) [B, Hs, Ws, 64]
+    const float* gcoef; BnFuse fuse;    // p0,p1,p2 rows (stride 64) / derive them here (BNF_BWD; workgroup 0 records them)
+    const T* wp;                        // packed dgrad weights [9][64/8][32][8]
+    const T* yprev; const float* ocoef; // previous layer (high-res side) [B, 2Hs, 2Ws, 32]; its block rows LC_* (stride 32)
+    T* dzprev; double* stat;            // outputs: dz of the previous layer; [sum dz | sum dz*xhat] (replicated, 2*32)
+    float* slab;                        // [gridDim.x][9][64][32] partial weight gradients
+    float slope;
+    int B, Hs, Ws, n_tiles, tiles_x, tiles_y, rev;
+    int ablate;                         // diagnostics (timing only, results wrong): 1 no matrix phase, 2 no epilogue, 4 no staging, 8 no reloads
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_bwd_fused_kernel(ConvFusedArgs<T> a) {
+    static_assert(sizeof(T) == 2, "16-bit storage only (f32 keeps the separate kernels)");
+    typedef typename H16<T>::v8 T8;
+    constexpr int CLO = 64, TH = 8, TW = 8, NLO = TH * TW;                 // 64 low-res pixels
+    constexpr int LPH = TH + 1, LPW = TW + 1, NLP = LPH * LPW;             // 9 x 9 low-res patch of g
+    constexpr int HT = 2 * TH, WT = 2 * TW, NHI = HT * WT;                 // 16 x 16 high-res output tile
+    constexpr int HPH = HT + 1, HPW = WT + 1, NHP = HPH * HPW;             // 17 x 17 high-res patch of a_prev
+    constexpr int LP = CLO * 2 + 16, HP = 80;                              // LDS pitches (bytes per pixel)
+    constexpr int NGC = NLP * 8, NG = (NGC + 511) / 512;                   // g chunks (8 per pixel): 648, 2 per thread
+    constexpr int NAC = NHP * 4, NA = (NAC + 511) / 512;                   // a_prev chunks (4 per pixel): 1156, 3 per thread
+    constexpr int NWT = 3;                                                 // weight-gradient tiles per wgrad wave (18 over waves 2..7)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gpatch = smem;                                  // [NLP][LP]  g
+    char* apatch = gpatch + NLP * LP;                     // [NHP][HP]  a_prev (zero outside the image)
+    char* ytile = apatch + NHP * HP;                      // [NHI][HP]  raw y_prev of the output tile -> dz_prev in place
+    char* wlds = ytile + NHI * HP;                        // [9][8][32][8] dgrad weights
+    float* cfg = reinterpret_cast<float*>(wlds + 9 * 8 * 32 * 16);   // [3][64] p0,p1,p2 of this layer
+    float* cfa = cfg + 3 * CLO;                           // [2][32] scale, shift of the previous layer's BatchNorm
+    float* red = cfa + 64;                                // [4 waves][32][2]
+    // tile-independent chunk geometry, kept out of the registers: {element offset relative to the patch origin,
+    // LDS offset | py << 16 | px << 24}; g chunks first (NG * 512), then a_prev chunks (NA * 512)
+    int2* ctab = reinterpret_cast<int2*>(red + 4 * 32 * 2);
+    constexpr int FP = 32 * 4 + 16;                       // f32 accumulator tile pitch
+    char* ftile = reinterpret_cast<char*>(ctab + (NG + NA) * 512);   // [NHI][FP] input-gradient accumulators (f32)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int Hg = 2 * a.Hs, Wg = 2 * a.Ws;
+
+    // ---- prologue
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int id = tid + 512 * u, pix = id >> 3, py = pix / LPW, px = pix - py * LPW;
+        ctab[id] = make_int2((py * a.Ws + px) * CLO + (id & 7) * 8, (id < NGC ? pix * LP + (id & 7) * 16 : 0xffff) | (py << 16) | (px << 24));
+    }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int id = tid + 512 * u, pix = id >> 2, py = pix / HPW, px = pix - py * HPW;
+        ctab[NG * 512 + id] = make_int2((py * Wg + px) * 32 + (id & 3) * 8, (id < NAC ? pix * HP + (id & 3) * 16 : 0xffff) | (py << 16) | (px << 24));
+    }
+    if (tid < CLO) {
+        if (a.fuse.mode == BNF_BWD) bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cfg[tid], cfg[CLO + tid], cfg[2 * CLO + tid]);
+        else { cfg[tid] = a.gcoef[tid]; cfg[CLO + tid] = a.gcoef[CLO + tid]; cfg[2 * CLO + tid] = a.gcoef[2 * CLO + tid]; }
+    }
+    if (tid >= 64 && tid < 96) { const int n = tid - 64; cfa[n] = a.ocoef[LC_SC * 32 + n]; cfa[32 + n] = a.ocoef[LC_SH * 32 + n]; }
+    for (int i = tid; i < 9 * 8 * 32; i += 512)
+        *reinterpret_cast<T8*>(wlds + i * 16) = *reinterpret_cast<const T8*>(reinterpret_cast<const char*>(a.wp) + (size_t)i * 16);
+
+    auto tile_origin = [&](int t_, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        const int t = a.rev ? a.n_tiles - 1 - t_ : t_;
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y;
+        b = t / (a.tiles_x * a.tiles_y); y0 = ty * TH; x0 = tx * TW;
+    };
+    // chunk geometry (tile-independent): g chunk id = tid + 512u -> low-res patch pixel id>>3, channel eighth id&7;
+    // a chunk id -> high-res patch pixel id>>2, channel quarter id&3
+    T8 pz[NG], pyy[NG], pa[NA];
+    int gok = 0, aok = 0;   // validity bits of the prefetched chunks
+    auto issue = [&](int t, bool have) __attribute__((always_inline)) {
+        int b, y0, x0; tile_origin(t, b, y0, x0);
+        gok = 0; aok = 0;
+        const int gbase = ((b * a.Hs + y0) * a.Ws + x0) * CLO, abase = ((b * Hg + 2 * y0 - 1) * Wg + 2 * x0 - 1) * 32;
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int2 e = ctab[tid + 512 * u];
+            const int py = (e.y >> 16) & 0xff, px = (e.y >> 24) & 0xff;
+            const bool ok = have && (e.y & 0xffff) != 0xffff && y0 + py < a.Hs && x0 + px < a.Ws;     // bottom / right halo beyond the image: zero
+            gok |= ok ? (1 << u) : 0;
+            const uint32_t off = ok ? (uint32_t)(gbase + e.x) * 2u : 0u;
+            pz[u] = *reinterpret_cast<const T8*>(at_bytes(a.dz, off));
+            pyy[u] = *reinterpret_cast<const T8*>(at_bytes(a.y, off));
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int2 e = ctab[NG * 512 + tid + 512 * u];
+            const int py = (e.y >> 16) & 0xff, px = (e.y >> 24) & 0xff;
+            const bool ok = have && (e.y & 0xffff) != 0xffff && (y0 > 0 || py > 0) && (x0 > 0 || px > 0);   // top / left halo outside the image: zero
+            aok |= ok ? (1 << u) : 0;
+            const uint32_t off = ok ? (uint32_t)(abase + e.x) * 2u : 0u;
+            pa[u] = *reinterpret_cast<const T8*>(at_bytes(a.yprev, off));
+        }
+    };
+
+    // ---- per-role state
+    const int wq = wave & 3;
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    // dgrad (waves 0..3): m tile wq & 1 (low-res pixel row R = m*32 + r), parity group wq >> 1
+    const int Rr = (wq & 1) * 32 + r, pbase = (Rr >> 3) * LPW + (Rr & 7);
+    f32x2 s1[4], s2[4];     // statistics of this thread's 8 channels ((tid & 3) * 8 ..): sum dz, sum dz*y
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+    // wgrad (waves 2..7, wj = wave - 2): tiles idx = wj + 6j < 18 -> tap idx >> 1, co block idx & 1 (= wj & 1)
+    const int wj = wave - 2;
+    const int acol = ((wj & 1) * 32 + 16 * (g4 & 1) + 4 * p) * 2, bcol = (16 * (g4 & 1) + 4 * p) * 2;
+    f32x16 wacc[NWT];
+#pragma unroll
+    for (int j = 0; j < NWT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wacc[j][i] = 0.f;
+    constexpr int tap_cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};     // out(2i+py,2j+px) <- in(i+di,j+dj) * W[tap]   (as up2_kernel)
+    constexpr int tap_t[9] = {4, 5, 3, 7, 1, 8, 6, 2, 0};
+    constexpr int tap_off[9] = {0, 0, 1, 0, 2, 0, 1, 2, 3};     // di*2 + dj
+
+    __syncthreads();
+    int t = blockIdx.x;
+    if (t < a.n_tiles) issue(t, true);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int b, y0, x0; tile_origin(t, b, y0, x0);
+        __syncthreads();                                   // (A) previous tile fully consumed
+        // ---- stage: g patch (BN backward on packed pairs), a_prev patch (BN + LeakyReLU), raw y_prev rows of the output tile
+        if (!(a.ablate & 4)) {
+            const int cg0 = (tid & 7) * 8;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int lo_ = ctab[tid + 512 * u].y & 0xffff;
+                T8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cg0 + 2 * e;
+                    const f32x2 k0 = *reinterpret_cast<const f32x2*>(cfg + c), k1 = *reinterpret_cast<const f32x2*>(cfg + CLO + c), k2 = *reinterpret_cast<const f32x2*>(cfg + 2 * CLO + c);
+                    const f32x2 x0_ = {(float)pz[u][2 * e], (float)pz[u][2 * e + 1]}, x1_ = {(float)pyy[u][2 * e], (float)pyy[u][2 * e + 1]};
+                    const f32x2 z = x0_ * k0 + (x1_ * k1 + k2);
+                    o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
+                }
+                if (!((gok >> u) & 1)) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (lo_ != 0xffff) *reinterpret_cast<T8*>(gpatch + lo_) = o;
+            }
+            const int ca0 = (tid & 3) * 8;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int ey_ = ctab[NG * 512 + tid + 512 * u].y, lo_ = ey_ & 0xffff, py = (ey_ >> 16) & 0xff, px = (ey_ >> 24) & 0xff;
+                T8 av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 sc2 = *reinterpret_cast<const f32x2*>(cfa + ca0 + 2 * e), sh2 = *reinterpret_cast<const f32x2*>(cfa + 32 + ca0 + 2 * e);
+                    f32x2 z = f32x2{(float)pa[u][2 * e], (float)pa[u][2 * e + 1]} * sc2 + sh2;
+                    const f32x2 zs = z * a.slope;
+                    z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+                    av[2 * e] = (T)z.x; av[2 * e + 1] = (T)z.y;
+                }
+                if (!((aok >> u) & 1)) av = T8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (lo_ != 0xffff) {
+                    *reinterpret_cast<T8*>(apatch + lo_) = av;
+                    if (py >= 1 && px >= 1) *reinterpret_cast<T8*>(ytile + lo_ - (HPW + py) * HP) = pa[u];   // raw y_prev of the tile: pixel (py-1)*WT + px-1
+                }
+            }
+        }
+        const int tn = t + (int)gridDim.x;
+        if (!(a.ablate & 8)) issue(tn < a.n_tiles ? tn : t, tn < a.n_tiles);    // next tile's loads fly during the matrix phase
+        __syncthreads();                                   // (B) patches published
+
+        if (wave < 4 && !(a.ablate & 1)) {
+            // ---- input gradient: 32 low-res pixels x the output parities of this wave's group
+            const bool grpB = wq < 2;                       // group B (waves 0,1): classes 0,1,2 (taps 0..4); group A (waves 2,3): class 3 (taps 5..8)
+            f32x16 dacc[3];
+#pragma unroll
+            for (int cI = 0; cI < 3; ++cI)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dacc[cI][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                Frag<T> af[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    af[o] = load_frag(reinterpret_cast<const T*>(gpatch + (pbase + (o >> 1) * LPW + (o & 1)) * LP + ks * 32) + h * 8);
+                if (grpB) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const Frag<T> bf = load_frag(reinterpret_cast<const T*>(wlds + (((tap_t[k] * 8 + 2 * ks + h) * 32 + r) * 16)));
+                        mma(dacc[tap_cls[k]], af[tap_off[k]], bf);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 5; k < 9; ++k) {
+                        const Frag<T> bf = load_frag(reinterpret_cast<const T*>(wlds + (((tap_t[k] * 8 + 2 * ks + h) * 32 + r) * 16)));
+                        mma(dacc[0], af[tap_off[k]], bf);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue in place: class c = py*2 + px -> high-res pixel (2*ty + py, 2*tx + px) of the tile
+            // accumulator element i of lane (r, h) is low-res pixel (4m + (i >> 2), 4h + (i & 3)) of the tile: class (py, px) puts it
+            // at high-res pixel (2*row + py, 2*col + px): a per-lane base plus a compile-time constant
+            char* fbase = ftile + (((wq & 1) * 8) * WT + 8 * h) * FP + r * 4;
+            auto put_class = [&](const f32x16& acc, int cls) __attribute__((always_inline)) {
+                const int cpy = cls >> 1, cpx = cls & 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    *reinterpret_cast<float*>(fbase + ((2 * (i >> 2) + cpy) * WT + 2 * (i & 3) + cpx) * FP) = acc[i];
+            };
+            if (grpB) { put_class(dacc[0], 0); put_class(dacc[1], 1); put_class(dacc[2], 2); }
+            else put_class(dacc[0], 3);
+        }
+        if (wave >= 2 && !(a.ablate & 1)) {
+            // ---- weight gradient: A = g^T (k-major reads of the patch's 64 centre pixels), B = a_prev at the tap's high-res pixels
+#pragma unroll
+            for (int j = 0; j < NWT; ++j) {
+                const int idx = wj + 6 * j;
+                {
+                    const int tp = idx >> 1, toff = (tp / 3) * HPW + (tp % 3);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int kk0 = ks * 16 + 8 * (g4 >> 1) + q, kk1 = kk0 + 4;
+                        const int ga0 = (kk0 >> 3) * LPW + (kk0 & 7), ga1 = (kk1 >> 3) * LPW + (kk1 & 7);
+                        const int gb0 = (2 * (kk0 >> 3)) * HPW + 2 * (kk0 & 7), gb1 = (2 * (kk1 >> 3)) * HPW + 2 * (kk1 & 7);
+                        const Frag<T> af = frag_tr16<T>(gpatch + ga0 * LP + acol, gpatch + ga1 * LP + acol);
+                        const Frag<T> bf = frag_tr16<T>(apatch + (gb0 + toff) * HP + bcol, apatch + (gb1 + toff) * HP + bcol);
+                        mma(wacc[j], af, bf);
+                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // (C) accumulator tile complete
+        // ---- epilogue in chunk layout: 1024 chunks (16 x 16 pixels x 4 channel quarters), 2 per thread; the tile leaves as 16
+        // rows of 1 KiB
+        if (!(a.ablate & 2)) {
+            const int qq = tid & 3;
+            f32x2 esc2[4], esh2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { esc2[e] = *reinterpret_cast<const f32x2*>(cfa + qq * 8 + 2 * e); esh2[e] = *reinterpret_cast<const f32x2*>(cfa + 32 + qq * 8 + 2 * e); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pix = (tid + 512 * u) >> 2;
+                const T8 yv8 = *reinterpret_cast<const T8*>(ytile + pix * HP + qq * 16);
+                const f32x4 a0_ = *reinterpret_cast<const f32x4*>(ftile + pix * FP + qq * 32), a1_ = *reinterpret_cast<const f32x4*>(ftile + pix * FP + qq * 32 + 16);
+                T8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 yv = {(float)yv8[2 * e], (float)yv8[2 * e + 1]};
+                    const f32x2 z = yv * esc2[e] + esh2[e];
+                    f32x2 g = e < 2 ? f32x2{a0_[2 * e], a0_[2 * e + 1]} : f32x2{a1_[2 * e - 4], a1_[2 * e - 3]};
+                    g.x = z.x > 0.f ? g.x : g.x * a.slope; g.y = z.y > 0.f ? g.y : g.y * a.slope;
+                    T o0, o1;
+                    const f32x2 dzv = round_pair<T>(g, o0, o1);
+                    o[2 * e] = o0; o[2 * e + 1] = o1;
+                    s1[e] += dzv; s2[e] += dzv * yv;
+                }
+                const uint32_t off = (uint32_t)(((b * Hg + 2 * y0 + (pix >> 4)) * Wg + 2 * x0 + (pix & 15)) * 32 + qq * 8) * 2u;
+                *reinterpret_cast<T8*>(at_bytes(a.dzprev, off)) = o;
+            }
+        }
+    }
+
+    // ---- workgroup results: statistics (every thread holds partial sums of its 8 channels: lanes with equal tid & 3 share
+    // them), weight-gradient slab
+    float* redw = reinterpret_cast<float*>(ftile);        // [8 waves][32][2] (the accumulator tile is free now)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v[4] = {s1[e].x, s1[e].y, s2[e].x, s2[e].y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
+        }
+        if (lane < 4) {
+            const int c = lane * 8 + 2 * e;
+            redw[(wave * 32 + c) * 2] = v[0]; redw[(wave * 32 + c + 1) * 2] = v[1];
+            redw[(wave * 32 + c) * 2 + 1] = v[2]; redw[(wave * 32 + c + 1) * 2 + 1] = v[3];
+        }
+    }
+    if (wave >= 2) {
+#pragma unroll
+        for (int j = 0; j < NWT; ++j) {
+            const int idx = wj + 6 * j;
+            {
+                const int tp = idx >> 1, cib = idx & 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    a.slab[(((size_t)blockIdx.x * 9 + tp) * CLO + cib * 32 + acc_row(i, lane)) * 32 + r] = wacc[j][i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { v1 += redw[(w * 32 + tid) * 2]; v2 += redw[(w * 32 + tid) * 2 + 1]; }
+        v2 = a.ocoef[LC_INVSTD * 32 + tid] * v2 + a.ocoef[LC_XM * 32 + tid] * v1;   // sum dz*xhat from sum dz*y and sum dz
+        double* st_ = a.stat + stat_rep() * 64;
+        unsafeAtomicAdd(&st_[tid], (double)v1);
+        unsafeAtomicAdd(&st_[32 + tid], (double)v2);
+    }
+}
+
+static inline size_t conv_fused_lds() {
+    return (size_t)81 * (64 * 2 + 16) + (size_t)289 * 80 + (size_t)256 * 80 + (size_t)9 * 8 * 32 * 16 + (size_t)(3 * 64 + 64 + 4 * 32 * 2) * 4 + (size_t)5 * 512 * 8 + (size_t)256 * (32 * 4 + 16);
+}

@@ -150,7 +150,7 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     if (ok) { c->reduce_tmp_floats = 64 * 1024; c->reduce_tmp = dalloc<float>(c, c->reduce_tmp_floats); ok = c->reduce_tmp != nullptr; }
     if (ok && dtype != VAE_DTYPE_F32) {
         c->fused_slab_floats = (size_t)512 * 9 * 64 * 32;   // up to 512 workgroups x [9][64][32]
-        for (int i = 0; i < 2 && ok; ++i) { c->fused_slab[i] = dalloc<float>(c, c->fused_slab_floats); ok = c->fused_slab[i] != nullptr; }
+        for (int i = 0; i < 3 && ok; ++i) { c->fused_slab[i] = dalloc<float>(c, c->fused_slab_floats); ok = c->fused_slab[i] != nullptr; }
     }
     if (!ok) { vae_set_error("vae_create", "hipMalloc failed"); vae_destroy(c); return nullptr; }
     std::vector<float> id(3 * 256, 0.f);
@@ -179,8 +179,9 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_conv1_grid")) { c->knob_conv1_grid = value; return 0; }
     if (!strcmp(name, "knob_rev")) { c->knob_rev = value; return 0; }
     if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
-    if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value; return 0; }
+    if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value == 1 ? 3 : (value == 2 ? 1 : (value == 3 ? 2 : 0)); return 0; }   // 1 all, 2 decoder side only, 3 encoder.1 only
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
+    if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }
     if (!strcmp(name, "knob_fused_grid")) { c->knob_fused_grid = std::max(1, std::min(value, 512)); return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { c->wk.tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { c->wk.wide = value; return 0; }

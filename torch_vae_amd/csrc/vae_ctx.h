@@ -77,12 +77,13 @@ struct vae_ctx {
     double* generic_accum;                           // vae_elbo_generic on this context's device (per context, not process-global)
     WgradKnobs wk;
     float* reduce_tmp = nullptr; size_t reduce_tmp_floats = 0; unsigned reduce_slot = 0;   // partial sums of the two-level slab reduction
-    float* fused_slab[2] = {nullptr, nullptr}; size_t fused_slab_floats = 0;   // split-K slabs of the fused dgrad+wgrad kernels (layers 7, 6)
+    float* fused_slab[3] = {nullptr, nullptr, nullptr}; size_t fused_slab_floats = 0;   // split-K slabs of the fused dgrad+wgrad kernels (layers 7, 6, 1)
     // use_recomp_dz: final_layer.0's dz recomputed from dlogit instead of stored (conv_fused.cuh RECOMP).  Bit-identical and
     // 268 MB less traffic each way, but measured SLOWER on MI355X (1.50 vs 1.33 ms/step): the per-element BatchNorm-backward in
     // accumulator layout costs ~20 VALU per element, and the output-conv backward is VALU-bound, not write-bound (134 us without
     // the store, 128 us with it).  Off by default; kept for the day both epilogues are cheap.
-    int use_fused_wgrad = 1, knob_fused_grid = 256, use_recomp_dz = 0;
+    int knob_ablate_f = 0;   // diagnostics: phase ablation of conv_bwd_fused_kernel (timing only)
+    int use_fused_wgrad = 3, knob_fused_grid = 256, use_recomp_dz = 0;   // use_fused_wgrad: bit 0 decoder (ConvT) kernels, bit 1 encoder.1 kernel
     // f16 storage: the backward runs on gradients multiplied by gmul (a power of two chosen per forward so that the stored
     // dz stay inside the f16 range: the BCE mean makes them O(1/(B*H*W))); every parameter gradient is written times ginv.
     // The backward is linear in the upstream gradient, so this changes no f32 result (powers of two are exact).  1 otherwise.

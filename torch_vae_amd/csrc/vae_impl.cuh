@@ -427,7 +427,7 @@ static bool convt_fused_ok(vae_ctx* c, int i) {
     if (sizeof(T) != 2) return false;
     const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
     const int Hs = l.H / 2, Ws = l.W / 2, CLO = lp.C;
-    if (!c->use_fused_wgrad || !c->use_pipelined || l.C != 32 || (CLO != 32 && CLO != 64) || Hs % 8 || Ws % 16) return false;
+    if (!(c->use_fused_wgrad & 1) || !c->use_pipelined || l.C != 32 || (CLO != 32 && CLO != 64) || Hs % 8 || Ws % 16) return false;
     if (4.0 * c->B * Hs * Ws * 32 * sizeof(T) >= 4294967296.0 || 1.0 * c->B * Hs * Ws * CLO * sizeof(T) >= 4294967296.0) return false;   // 32-bit byte offsets
     const int grid = std::min(c->B * (Ws / 16) * (Hs / 8), c->knob_fused_grid);
     return (size_t)grid * 9 * CLO * 32 <= c->fused_slab_floats;
@@ -469,6 +469,42 @@ static int launch_convt_fused(vae_ctx* c, int i, const float* params, float* gra
         SideFork f = fork_side(c, st);
         if (f.rc) return -1;
         if (launch_reduce(a.slab, grid, (size_t)9 * CLO * 32, grads + c->poff[l.p_convw], CLO, 32, f.st, c)) return -1;
+        return 0;
+    }
+}
+
+// Fused input + weight gradient of encoder.1 (Conv2d 32 -> 64 with the 32-channel tensor on the high-res side; conv_fused.cuh).
+// Returns 1 when outside the fused kernel's domain (the caller takes the separate kernels), 0 on success, -1 on error.
+template <typename T>
+static int launch_conv_fused(vae_ctx* c, int i, const float* params, float* grads, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return 1;
+    else {
+        const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
+        const int Hs = l.H, Ws = l.W;
+        if (!(c->use_fused_wgrad & 2) || !c->use_pipelined || l.C != 64 || lp.C != 32 || Hs % 8 || Ws % 8) return 1;
+        if (4.0 * c->B * Hs * Ws * 32 * sizeof(T) >= 4294967296.0 || 1.0 * c->B * Hs * Ws * 64 * sizeof(T) >= 4294967296.0) return 1;   // 32-bit byte offsets
+        ConvFusedArgs<T> a; memset(&a, 0, sizeof(a));
+        a.tiles_x = Ws / 8; a.tiles_y = Hs / 8; a.n_tiles = c->B * a.tiles_x * a.tiles_y;
+        const int grid = std::min(a.n_tiles, c->knob_fused_grid);
+        if ((size_t)grid * 9 * 64 * 32 > c->fused_slab_floats) return 1;
+        a.dz = reinterpret_cast<const T*>(l.dz); a.y = reinterpret_cast<const T*>(l.y); a.gcoef = l.block + LC_P0 * l.C;
+        a.fuse = make_fuse_bwd(c, i, params, grads);
+        if (!c->use_fused_bn) { if (bn_finalize_now(c, a.fuse, st)) return -1; a.fuse.mode = BNF_NONE; }
+        a.wp = reinterpret_cast<const T*>(c->wp_dg[i]);
+        a.yprev = reinterpret_cast<const T*>(lp.y); a.ocoef = lp.block; a.dzprev = reinterpret_cast<T*>(lp.dz); a.stat = lp.stat_b;
+        a.slab = c->fused_slab[2]; a.slope = kSlope; a.B = c->B; a.Hs = Hs; a.Ws = Ws; a.rev = (c->knob_rev >> 2) & 1; a.ablate = c->knob_ablate_f;
+        const size_t lds = conv_fused_lds();
+        const double px = (double)c->B * Hs * Ws;
+        {
+            ProfScope ps(c, "conv_bwd_fused(dgrad+wgrad)", sizeof(T) * (2.0 * px * 64 + 2.0 * 4 * px * 32 + 9.0 * 32 * 64) + 4.0 * 9 * 32 * 64,
+                         2.0 * 2 * 9 * 32 * 64 * px, st);
+            if (set_lds(conv_bwd_fused_kernel<T>, lds)) return -1;
+            hipLaunchKernelGGL((conv_bwd_fused_kernel<T>), dim3(grid), dim3(512), lds, st, a);
+            LAUNCH_CHECK("conv_bwd_fused_kernel");
+        }
+        SideFork f = fork_side(c, st);
+        if (f.rc) return -1;
+        if (launch_reduce(a.slab, grid, (size_t)9 * 64 * 32, grads + c->poff[l.p_convw], 64, 32, f.st, c)) return -1;
         return 0;
     }
 }
@@ -651,6 +687,11 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
     // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
     for (int i = 3; i >= 1; --i) {
         c->tag = kLayerTag[i];
+        if (i == 1) {   // 32-channel high-res side: one pass for both gradients
+            const int rc = launch_conv_fused<T>(c, i, params, grads, st);
+            if (rc < 0) return -1;
+            if (rc == 0) continue;
+        }
         const BnLayer& l = c->lay[i]; const BnLayer& lp = c->lay[i - 1];
         WgradArgs<T> w; memset(&w, 0, sizeof(w));
         w.s0 = reinterpret_cast<const T*>(l.dz); w.s1 = reinterpret_cast<const T*>(l.y); w.scoef = l.block + LC_P0 * l.C; w.sslope = 1.f; w.s_two = 1;
