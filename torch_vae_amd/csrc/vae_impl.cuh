@@ -131,8 +131,9 @@ static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int
     if (nslab >= 256 && n * 32 * 4 <= c->reduce_tmp_floats) {
         const int G = 32, per = (nslab + G - 1) / G;
         // (reductions on different streams may be in flight together: each takes the next of the buffer's slots)
-        const size_t nslots = c->reduce_tmp_floats / (n * G);
-        float* tmp = c->reduce_tmp + (size_t)(c->reduce_slot++ % nslots) * n * G;
+        constexpr size_t kSlot = 16384;     // fixed slot stride: reductions of different sizes must never overlap
+        if (n * G > kSlot) return vae_set_error("reduce", "two-level scratch slot too small");
+        float* tmp = c->reduce_tmp + (size_t)(c->reduce_slot++ % (c->reduce_tmp_floats / kSlot)) * kSlot;
         hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64), G), dim3(256), 0, st, slab, nslab, (int)n, tmp, 0, 0, 1.f, per);
         LAUNCH_CHECK("reduce_slab_kernel");
         hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, tmp, G, (int)n, out, CA, CB, c->ginv, G);
