@@ -981,3 +981,28 @@ def test_fused_dgrad_wgrad_matches_separate_kernels(cfg):
     np.testing.assert_array_equal(res[1][3], res[3][3])                       # encoder.1 fused vs separate on identical inputs: bit-identical dz
     assert rel_l2(res[1][2]["encoder.1.0.weight"], res[3][2]["encoder.1.0.weight"]) < 2e-5
     assert rel_l2(res[1][2]["encoder.0.1.weight"], res[3][2]["encoder.0.1.weight"]) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [(64, 16, 5, "bf16"), (128, 16, 3, "f16"), (32, 16, 33, "bf16")])
+def test_materialised_operands_weight_gradients_match(cfg):
+    """Deep layers (encoder.2/3, decoder.0/1): the weight-gradient kernel reading the MATERIALISED operands (LeakyReLU(BN(y)) written by
+    the forward kernel that stages it, the BatchNorm-backward gradient written by the input-gradient kernel) against the same
+    kernel transforming its operands itself: identical operand values, identical tiling - nothing in the step may change."""
+    from torch_vae_amd import _lib
+    H, L, B, dtype = cfg
+    p = perturbed_params(L, H, 31, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 37)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 37, 5).reshape(B, L)).float().cuda()
+    res = []
+    for raw in (0, 1):
+        model = make_model(H, L, True, dtype, p)
+        model._context(B)
+        assert _lib.lib().vae_set_option(model._ctx.handle, b"use_raw_wgrad", raw) == 0
+        out3, _ = model.fused_forward_backward(x, eps=eps)
+        res.append((out3.cpu().numpy(), flat_grad_dict(model)))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        if n in ("encoder.2.0.weight", "encoder.3.0.weight", "decoder.0.0.weight", "decoder.1.0.weight"):
+            assert rel_l2(res[1][1][n], res[0][1][n]) < 1e-6, (n, rel_l2(res[1][1][n], res[0][1][n]))
+        else:
+            np.testing.assert_array_equal(res[1][1][n], res[0][1][n], err_msg=n)

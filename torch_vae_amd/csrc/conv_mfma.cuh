@@ -37,6 +37,10 @@ template <typename T> struct ConvArgs {
     long long* dbg;                                                // diagnostic builds only: per-wave phase cycle counters
     BnFuse fuse;                                                   // mode != 0: derive the staging coefficients from batch statistics (pipelined kernels)
     int rev, n_mt;                                                 // walk the M tiles in reverse order (n_mt of them)
+    // pipelined kernels: when set, every staged (transformed, storage-rounded) chunk a tile OWNS (its non-halo pixels, N tile 0)
+    // is also written here, in the source tensor's layout: the materialised activation / BatchNorm-backward gradient that the
+    // deep layers' weight-gradient kernels then read without any staging arithmetic
+    T* stage_out;
 };
 
 // x / d for small x via one mul_hi: m = ceil(2^32 / d), exact for x, d < 2^16
@@ -368,8 +372,10 @@ __device__ __forceinline__ Frag<T> frag_tr16(const char* ad0, const char* ad1) {
 // the matrix pipe (persistent loop over this workgroup's K tiles).  CONVT selects which side carries
 // the two-source gradient operand (ConvTranspose2d: high-res side; Conv2d: low-res side).
 // NW = waves per workgroup (4, or 8 for the 128x32-channel tile of the wide layers: twice the channels per staged byte).
-template <typename T, int WA, int WB, bool CONVT, bool PRE, int NW = 4>
+// RAW (prefetching variants): both operands are materialised (already transformed and rounded): staged as plain copies.
+template <typename T, int WA, int WB, bool CONVT, bool PRE, int NW = 4, bool RAW = false>
 __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4) ? 2 : 1)) void wgrad_kernel(WgradArgs<T> a) {
+    static_assert(!RAW || PRE, "RAW operands: prefetching variants only");
     // NW waves = WA x WB channel blocks x TS tap groups; a wave owns taps ts, ts+TS, ... (no cross-wave sum)
     static_assert(NW == 4 || PRE, "the 8-wave layout exists for the prefetching variant only");
     constexpr int NTHR = 64 * NW, SIT = WG_KP * 4 * WA / NTHR;   // threads; low-res chunks per thread
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
     constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
     constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
-    constexpr bool S_TWO = !CONVT, G_TWO = CONVT;
+    constexpr bool S_TWO = !CONVT && !RAW, G_TWO = CONVT && !RAW;
     constexpr int MAXG = (5 * WB * 256 + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -404,6 +410,10 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
     }
 
     // staging coefficients (tile-local rows); the gradient operand's may be derived here from the batch statistics
+    if constexpr (RAW) {   // identity (the synchronous remainder path still goes through the transform helper)
+        for (int i = tid; i < 3 * 32 * WA; i += NTHR) cfs[i] = i < 32 * WA ? 1.f : 0.f;
+        for (int i = tid; i < 3 * 32 * WB; i += NTHR) cfg[i] = i < 32 * WB ? 1.f : 0.f;
+    } else {
     if (a.fuse.mode == BNF_BWD && a.s_two) {
         for (int i = tid; i < 32 * WA; i += NTHR) bn_fused_channel(a.fuse, a0 + i, false, cfs[i], cfs[32 * WA + i], cfs[2 * 32 * WA + i]);
     } else {
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
         for (int i = tid; i < 32 * WB; i += NTHR) bn_fused_channel(a.fuse, bc0 + i, false, cfg[i], cfg[32 * WB + i], cfg[2 * 32 * WB + i]);
     } else {
         for (int i = tid; i < 3 * 32 * WB; i += NTHR) cfg[i] = a.gcoef[(i / (32 * WB)) * CB + bc0 + (i % (32 * WB))];
+    }
     }
 
     f32x16 acc[NTW];
@@ -475,6 +486,7 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
     // v0*k0 (+ v1*k1) + k2, LeakyReLU on the activation operand; pairs -> packed f32 math
     auto xform2 = [&](const Vec16<T>& v0, const Vec16<T>& v1, const f32x2* k0, const f32x2* k1, const f32x2* k2, bool two, float slope)
         __attribute__((always_inline)) {
+        if constexpr (RAW) return v0;
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < NE / 2; ++e) {

@@ -227,8 +227,11 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
             Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
-            if (!item_ok(g, it, e[u].y)) o = zero_vec16<T>();
+            const bool ok_ = item_ok(g, it, e[u].y);
+            if (!ok_) o = zero_vec16<T>();
             if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((e[u].y & 0x1fff) << 4)) = o;
+            if (a.stage_out && ok_ && g.n0 == 0 && !(e[u].y & (3 << 13)) && it < nitems)   // owned (non-halo) chunk: materialise it
+                *reinterpret_cast<Vec16<T>*>(at_bytes(a.stage_out, (uint32_t)(tile_base(g, c0) + e[u].x) * (uint32_t)sizeof(T))) = o;
             const uint32_t gi = (nhave_ & item_ok(gn, it, e[u].y)) ? (uint32_t)(nbase + e[u].x) : 0u;
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
@@ -240,6 +243,8 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
             Vec16<T> v = zero_vec16<T>();
             if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, (size_t)(tile_base(g, c0) + e.x), cf, Cin, c0 + (it & 3) * E16, a.slope);
             *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
+            if (a.stage_out && ok && g.n0 == 0 && !(e.y & (3 << 13)))
+                *reinterpret_cast<Vec16<T>*>(at_bytes(a.stage_out, (uint32_t)(tile_base(g, c0) + e.x) * (uint32_t)sizeof(T))) = v;
         }
     };
     // out-tile chunk u of this lane (wave-local chunk id = lane + 64u): the tile-independent part of its address is
@@ -543,8 +548,11 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         for (int u = 0; u < MAXI; ++u) {
             const int it = stid + u * SSTR;
             Vec16<T> o = xform(pre0[u], pre1[TWO_SRC ? u : 0]);
-            if (!item_ok(g, it, e[u].y)) o = zero_vec16<T>();
+            const bool ok_ = item_ok(g, it, e[u].y);
+            if (!ok_) o = zero_vec16<T>();
             if (it < nitems) *reinterpret_cast<Vec16<T>*>(patch + ((e[u].y & 0x1fff) << 4)) = o;
+            if (a.stage_out && ok_ && g.n0 == 0 && !(e[u].y & (3 << 13)) && it < nitems)   // owned (non-halo) chunk: materialise it
+                *reinterpret_cast<Vec16<T>*>(at_bytes(a.stage_out, (uint32_t)(tile_base(g, c0) + e[u].x) * (uint32_t)sizeof(T))) = o;
             const uint32_t gi = (nhave_ & item_ok(gn, it, e[u].y)) ? (uint32_t)(nbase + e[u].x) : 0u;
             pre0[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src0, gi * (uint32_t)sizeof(T)));
             if constexpr (TWO_SRC) pre1[u] = *reinterpret_cast<const Vec16<T>*>(at_bytes(a.src1, gi * (uint32_t)sizeof(T)));
@@ -555,6 +563,8 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             Vec16<T> v = zero_vec16<T>();
             if (ok) v = load_transform16<T>(a.src0, a.src1, TWO_SRC, (size_t)(tile_base(g, c0) + e.x), cf, Cin, c0 + (it & 3) * E16, a.slope);
             *reinterpret_cast<Vec16<T>*>(patch + ((e.y & 0x1fff) << 4)) = v;
+            if (a.stage_out && ok && g.n0 == 0 && !(e.y & (3 << 13)))
+                *reinterpret_cast<Vec16<T>*>(at_bytes(a.stage_out, (uint32_t)(tile_base(g, c0) + e.x) * (uint32_t)sizeof(T))) = v;
         }
     };
     // round py: wave-local out pixel o = 2*row + px (row = base pixel 0..31) -> LDS row o, global (2i+py, 2j+px).

@@ -147,6 +147,13 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
             c->n_side_ok = ok ? 1 : 0;
         }
     }
+    if (ok && dtype != VAE_DTYPE_F32) {   // materialised operands of the deep weight gradients (small tensors)
+        for (int i = 1; i <= 5 && ok; ++i) {
+            const size_t n = B * c->lay[i].H * c->lay[i].W * c->lay[i].C;
+            if (i == 1 || i == 2 || i == 4) { c->lay[i].act = dalloc<char>(c, n * c->esz); ok = ok && c->lay[i].act; }
+            if (i >= 2) { c->lay[i].dy = dalloc<char>(c, n * c->esz); ok = ok && c->lay[i].dy; }
+        }
+    }
     if (ok) { c->reduce_tmp_floats = 64 * 1024; c->reduce_tmp = dalloc<float>(c, c->reduce_tmp_floats); ok = c->reduce_tmp != nullptr; }
     if (ok && dtype != VAE_DTYPE_F32) {
         c->fused_slab_floats = (size_t)512 * 9 * 64 * 32;   // up to 512 workgroups x [9][64][32]
@@ -182,6 +189,8 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value == 1 ? 3 : (value == 2 ? 1 : (value == 3 ? 2 : 0)); return 0; }   // 1 all, 2 decoder side only, 3 encoder.1 only
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }
+    if (!strcmp(name, "knob_skip_wgrad")) { c->knob_skip_wgrad = value; return 0; }
+    if (!strcmp(name, "use_raw_wgrad")) { c->use_raw_wgrad = value; return 0; }
     if (!strcmp(name, "knob_fused_grid")) { c->knob_fused_grid = std::max(1, std::min(value, 512)); return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { c->wk.tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { c->wk.wide = value; return 0; }

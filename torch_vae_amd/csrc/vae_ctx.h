@@ -40,6 +40,9 @@ struct BnLayer {
     int C, H, W;            // spatial size of the tensor this BN normalises
     double* stat_f; double* stat_b; float* block; void* y; void* dz;
     int p_gamma, p_beta, p_convw, p_convb;
+    // deep layers, 16-bit storage: materialised LeakyReLU(BN(y)) / BatchNorm-backward gradient g (written as a side effect by the
+    // pipelined kernel that stages the tensor first) for the weight-gradient kernels; *_ok: valid for the current forward / backward
+    void* act = nullptr; void* dy = nullptr; int act_ok = 0, dy_ok = 0;
 };
 
 // weight packing descriptors (pack_kernel, edge_kernels.cuh): f32 reference layouts -> MFMA B-operand images of T
@@ -82,6 +85,11 @@ struct vae_ctx {
     // 268 MB less traffic each way, but measured SLOWER on MI355X (1.50 vs 1.33 ms/step): the per-element BatchNorm-backward in
     // accumulator layout costs ~20 VALU per element, and the output-conv backward is VALU-bound, not write-bound (134 us without
     // the store, 128 us with it).  Off by default; kept for the day both epilogues are cheap.
+    // use_raw_wgrad: deep layers' weight gradients read MATERIALISED operands (LeakyReLU(BN(y)) / BN-backward gradient written as a
+    // side effect by the kernel that stages them first) as plain copies.  Bit-identical; measured 1 % SLOWER in the step on MI355X
+    // (the extra stores cost the chain more than the weight-gradient kernels gain: their time is not in the staging arithmetic).
+    int use_raw_wgrad = 0;
+    int knob_skip_wgrad = 0;  // diagnostics: bit i skips the separate weight-gradient launch of BN layer i (results wrong, timing only)
     int knob_ablate_f = 0;   // diagnostics: phase ablation of conv_bwd_fused_kernel (timing only)
     int use_fused_wgrad = 3, knob_fused_grid = 256, use_recomp_dz = 0;   // use_fused_wgrad: bit 0 decoder (ConvT) kernels, bit 1 encoder.1 kernel
     // f16 storage: the backward runs on gradients multiplied by gmul (a power of two chosen per forward so that the stored

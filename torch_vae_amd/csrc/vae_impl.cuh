@@ -145,8 +145,9 @@ static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int
     return 0;
 }
 
+// raw: both operands are materialised tensors (a.s0 low-res side, a.g0 high-res side), staged as plain copies
 template <typename T>
-static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st, float* slab_buf = nullptr) {
+static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t st, float* slab_buf = nullptr, bool raw = false) {
     if (!slab_buf) slab_buf = c->slab;
     int nsplit, tps, WA, WB;
     const bool big = (double)c->B * c->H * c->H >= (double)(1 << 21);   // e.g. 128x128 at batch >= 128
@@ -174,13 +175,15 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
                  sizeof(T) * (px_s * a.CA * (a.s_two ? 2 : 1) + 4 * px_s * a.CB * (a.g_two ? 2 : 1)) + 4.0 * 9 * a.CA * a.CB,
                  2.0 * 9 * a.CA * a.CB * px_s, st);
     // s_two/g_two identify the layer kind: Conv2d (gradient on the low-res side) or ConvTranspose2d
-    if (a.s_two == a.g_two) return vae_set_error("wgrad", "exactly one operand must be the gradient");
+    if (raw && !(WA == 4 && pre)) return vae_set_error("wgrad", "materialised operands: wide prefetching tile only");
+    if (!raw && a.s_two == a.g_two) return vae_set_error("wgrad", "exactly one operand must be the gradient");
     const bool convt = a.g_two != 0;
 #define WG_CASE(A_, B_, C_, P_) { if (set_lds(wgrad_kernel<T, A_, B_, C_, P_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_, C_, P_>), grid, dim3(256), lds, st, a); }
 #define WG_KIND(A_, B_, P_) { if (convt) WG_CASE(A_, B_, true, P_) else WG_CASE(A_, B_, false, P_) }
     if (WA == 4) {
         if constexpr (sizeof(T) == 2) {
-            if (convt) { if (set_lds(wgrad_kernel<T, 4, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, true, true, 8>), grid, dim3(512), lds, st, a); }
+            if (raw) { if (set_lds(wgrad_kernel<T, 4, 1, false, true, 8, true>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, false, true, 8, true>), grid, dim3(512), lds, st, a); }
+            else if (convt) { if (set_lds(wgrad_kernel<T, 4, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, true, true, 8>), grid, dim3(512), lds, st, a); }
             else { if (set_lds(wgrad_kernel<T, 4, 1, false, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, false, true, 8>), grid, dim3(512), lds, st, a); }
         }
     }
@@ -321,6 +324,10 @@ int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* b
         a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
         a.B = B; a.Hs = c->lay[i].H / 2; a.Ws = c->lay[i].W / 2; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
         if (i > 4 && input_bn_fwd(c, i - 1, params, bn_running, nbt, train, will_pipe(c, a), &a.fuse, st)) return -1;
+        if (i == 5) {
+            c->lay[4].act_ok = 0;
+            if (train && c->lay[4].act && raw_wgrad_ok<T>(c, 5) && will_pipe(c, a)) { a.stage_out = reinterpret_cast<T*>(c->lay[4].act); c->lay[4].act_ok = 1; }
+        }
         if (launch_up<T>(c, a, st)) return -1;
     }
     // output conv + sigmoid + reconstruction loss/gradient
@@ -394,6 +401,10 @@ int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* 
         a.out = reinterpret_cast<T*>(c->lay[i].y); a.stat = c->lay[i].stat_f;
         a.B = B; a.Hs = c->lay[i].H; a.Ws = c->lay[i].W; a.Cin = c->lay[i - 1].C; a.Cout = c->lay[i].C; a.epi = EPI_FWD;
         if (input_bn_fwd(c, i - 1, params, bn_running, nbt, train, will_pipe(c, a), &a.fuse, st)) return -1;
+        c->lay[i - 1].act_ok = 0;
+        if (train && i >= 2 && c->lay[i - 1].act && raw_wgrad_ok<T>(c, i) && will_pipe(c, a)) {   // materialise a_{i-1} for layer i's weight gradient
+            a.stage_out = reinterpret_cast<T*>(c->lay[i - 1].act); c->lay[i - 1].act_ok = 1;
+        }
         if (launch_down<T>(c, a, st)) return -1;
     }
     // fc_mu | fc_var, reparameterize
@@ -511,10 +522,15 @@ static int launch_conv_fused(vae_ctx* c, int i, const float* params, float* grad
 }
 
 template <typename T>
-static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t st) {
+static int wgrad_on_side(vae_ctx* c, WgradArgs<T> w, float* dw_out, hipStream_t st, bool raw = false) {
     SideFork f = fork_side(c, st);
     if (f.rc) return f.rc;
-    return launch_wgrad<T>(c, w, dw_out, f.st, f.slab);
+    return launch_wgrad<T>(c, w, dw_out, f.st, f.slab, raw);
+}
+// can the weight gradient of BN layer i (2..5) run on materialised operands?  (16-bit storage, wide prefetching tile)
+template <typename T>
+static bool raw_wgrad_ok(vae_ctx* c, int i) {
+    return sizeof(T) == 2 && c->use_raw_wgrad && c->use_pipelined && c->wk.wide && c->wk.tile == 1 && !c->wk.force_simple && i >= 2 && i <= 5;
 }
 
 template <typename T>
@@ -610,7 +626,18 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         BnFuse fb = make_fuse_bwd(c, i, params, grads);
         if (!(c->use_fused_bn && will_pipe(c, a))) { if (bn_finalize_now(c, fb, st)) return -1; fb.mode = BNF_NONE; }
         w.fuse = fb; a.fuse = fb;
-        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        // deep layers: the input-gradient kernel materialises g = BN-backward(dz, y) while staging it; the weight gradient then
+        // reads g and the forward's materialised activation as plain copies (it must follow the input-gradient launch)
+        const bool raw = raw_wgrad_ok<T>(c, i) && l.dy && will_pipe(c, a) && (i == 4 || c->lay[i - 1].act_ok);
+        if (raw) {
+            a.stage_out = reinterpret_cast<T*>(l.dy);
+            if (launch_down<T>(c, a, st)) return -1;
+            w.s0 = i == 4 ? reinterpret_cast<const T*>(c->d0) : reinterpret_cast<const T*>(c->lay[i - 1].act); w.s1 = nullptr; w.s_two = 0; w.sslope = 1.f;
+            w.g0 = reinterpret_cast<const T*>(l.dy); w.g1 = nullptr; w.g_two = 0; w.gslope = 1.f; w.fuse.mode = BNF_NONE;
+            if (!((c->knob_skip_wgrad >> i) & 1) && wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st, true)) return -1;
+            continue;
+        }
+        if (!((c->knob_skip_wgrad >> i) & 1) && wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;   // (knob: timing diagnostics)
         if (launch_down<T>(c, a, st)) return -1;
     }
     return 0;
@@ -706,7 +733,16 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         BnFuse fb = make_fuse_bwd(c, i, params, grads);
         if (!(c->use_fused_bn && will_pipe(c, a))) { if (bn_finalize_now(c, fb, st)) return -1; fb.mode = BNF_NONE; }
         w.fuse = fb; a.fuse = fb;
-        if (wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;
+        const bool raw = raw_wgrad_ok<T>(c, i) && l.dy && will_pipe(c, a) && lp.act_ok;
+        if (raw) {   // (as in the decoder loop)
+            a.stage_out = reinterpret_cast<T*>(l.dy);
+            if (launch_up<T>(c, a, st)) return -1;
+            w.s0 = reinterpret_cast<const T*>(l.dy); w.s1 = nullptr; w.s_two = 0; w.sslope = 1.f;
+            w.g0 = reinterpret_cast<const T*>(lp.act); w.g1 = nullptr; w.g_two = 0; w.gslope = 1.f; w.fuse.mode = BNF_NONE;
+            if (!((c->knob_skip_wgrad >> i) & 1) && wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st, true)) return -1;
+            continue;
+        }
+        if (!((c->knob_skip_wgrad >> i) & 1) && wgrad_on_side<T>(c, w, grads + c->poff[l.p_convw], st)) return -1;   // (knob: timing diagnostics)
         if (launch_up<T>(c, a, st)) return -1;
     }
     {
