@@ -84,13 +84,17 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 // LAY = 1 (workgroup tiles only, even NT): the 4 waves form a 2x2 grid over the 128-pixel x 32*NT-channel tile,
 // each computing 64 pixels x 16*NT channels, so every weight fragment a wave loads feeds two MFMAs - half the
 // weight traffic through the vector-memory pipe, which is what bounds the deep layers (wide N, few pixels).
+// LAY = 2: the same tile under EIGHT waves (2 x 4 grid, 64 pixels x 8*NT channels each, 512 threads): two waves per
+// SIMD, so one wave's staging / epilogue VALU and its waits run under the other's MFMAs (the SQ counters of the
+// 4-wave layout: matrix pipe 28 %, VALU 28 %, waiting 38 % of the cycles of the single wave per SIMD).
 template <typename T, int NT, int EPI, bool WV, int LAY = 0>
-__global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+__global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr bool TWO_SRC = EPI != EPI_FWD;
-    constexpr bool W22 = LAY == 1;
-    static_assert(!W22 || (!WV && NT % 2 == 0), "2x2 wave layout: workgroup tiles, even NT");
-    constexpr int MTW = W22 ? 2 : 1, NTW = W22 ? NT / 2 : NT, OROWS = 32 * MTW;   // per wave: M sub-tiles, N sub-tiles, out-tile rows
-    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = 10;
+    constexpr bool W22 = LAY >= 1;                       // waves form a 2 x WN grid over the workgroup tile
+    constexpr int NWV = LAY == 2 ? 8 : 4, NTHR = 64 * NWV, WN = LAY == 2 ? 4 : (LAY == 1 ? 2 : 1);
+    static_assert(!W22 || (!WV && NT % WN == 0), "wave-grid layouts: workgroup tiles, NT a multiple of the grid's N width");
+    constexpr int MTW = W22 ? 2 : 1, NTW = NT / WN, OROWS = 32 * MTW;   // per wave: M sub-tiles, N sub-tiles, out-tile rows
+    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = LAY == 2 ? 5 : 10;
     constexpr int OROW = 32 * NTW * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;  // out-tile row bytes / chunks
     constexpr int OPL = OROWS * OCH / 64;                                            // out chunks per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
     const int wm = W22 ? (wave & 1) : wv0, wn = W22 ? (wave >> 1) : 0;   // wave coordinates in the workgroup tile
     const int mrow0 = wm * OROWS;                                         // first tile pixel of this wave
-    constexpr int SSTR = WV ? 64 : 256;
+    constexpr int SSTR = WV ? 64 : NTHR;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = 2 * th + 1, PW = 2 * tw + 1, PP = PH * PW, npix = TB * PP, nitems = npix * 4;
     const int Hin = 2 * a.Hs, Win = 2 * a.Ws, Cin = a.Cin, Cout = a.Cout, NCH = Cin / CK;
@@ -106,12 +110,12 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     char* patch0 = smem + ((3 * Cin * 4 + 15) & ~15);
     char* patch = patch0 + (WV ? wave * npix * PATCH_PITCH : 0);
     char* otile = patch0 + (WV ? 4 : 1) * npix * PATCH_PITCH;                 // [4 waves][32 px][OPITCH]
-    float* red = reinterpret_cast<float*>(otile + 4 * OROWS * OPITCH);
+    float* red = reinterpret_cast<float*>(otile + NWV * OROWS * OPITCH);
     char* mytile = otile + wave * OROWS * OPITCH;
     // per-item staging table (tile-independent): {relative global element offset, LDS offset/16 | top<<13 | left<<14 | img<<15}
     int2* itab = reinterpret_cast<int2*>(red + 4 * NT * 32 * 2);
     // (padded to MAXI*SSTR entries; padding entries carry image 0xffff, which never passes the batch test)
-    for (int it = tid; it < max(nitems, MAXI * SSTR); it += 256) {
+    for (int it = tid; it < max(nitems, MAXI * SSTR); it += NTHR) {
         const int pix = it >> 2, q = it & 3;
         const int img = fastdiv(pix, a.m_pp), rem = pix - img * PP, py = fastdiv(rem, a.m_pw), px = rem - py * PW;
         itab[it] = it < nitems ? make_int2(((img * Hin + py) * Win + px) * Cin + q * E16,
@@ -120,9 +124,9 @@ __global__ __launch_bounds__(256, (NT > 1 ? 1 : 2)) void down2_kernel(ConvArgs<T
     }
 
     if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
-        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+        for (int i = tid; i < Cin; i += NTHR) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
     } else {
-        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+        for (int i = tid; i < 3 * Cin; i += NTHR) cf[i] = a.coef[i];
     }
 
     int pbase[MTW];
