@@ -633,7 +633,9 @@ def test_bench_two_rank_control_flow():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["roofline"]["achieved"] > 0
+    # (two ranks time-slice one GPU here, so a launch can take milliseconds and its GB/s round to 0.0: check the inputs)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64
+    assert out["roofline"]["algorithmic_bytes_per_launch"] > 0 and out["roofline"]["avg_launch_us"] > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------

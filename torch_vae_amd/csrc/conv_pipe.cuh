@@ -98,6 +98,9 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
     constexpr int OROW = 32 * NTW * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;  // out-tile row bytes / chunks
     constexpr int OPL = OROWS * OCH / 64;                                            // out chunks per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VAE_PHASE_STAMPS
+    const long long t_entry = clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
     const int wm = W22 ? (wave & 1) : wv0, wn = W22 ? (wave >> 1) : 0;   // wave coordinates in the workgroup tile
@@ -121,12 +124,6 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
         itab[it] = it < nitems ? make_int2(((img * Hin + py) * Win + px) * Cin + q * E16,
                                            ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == 0) << 13) | ((px == 0) << 14) | (img << 15))
                                : make_int2(0, 0xffff << 15);
-    }
-
-    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
-        for (int i = tid; i < Cin; i += NTHR) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-    } else {
-        for (int i = tid; i < 3 * Cin; i += NTHR) cf[i] = a.coef[i];
     }
 
     int pbase[MTW];
@@ -278,13 +275,18 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
     // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
     int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
     const int pstride = WV ? 4 * gridDim.x : gridDim.x;
+    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
+        for (int i = tid; i < Cin; i += NTHR) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += NTHR) cf[i] = a.coef[i];
+    }
     __syncthreads();                                       // staging table / coefficients published
     load_coefs(0);
     bool have = pi < n_pairs;
     TileGeo cur = decode_pair(a, have ? pi : 0, ntiles_n, 32 * NT);
     if (have) { issue(cur, 0); if (EPI == EPI_BWD) issue_y(cur); }
 #ifdef VAE_PHASE_STAMPS
-    long long tph[6] = {0, 0, 0, 0, 0, 0}; long long t0 = clock64();
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t0 = clock64(); tph[6] = t0 - t_entry;
 #endif
 #ifdef VAE_PHASE_STAMPS   // diagnostic build (make STAMPS=1): the stamps split the loop body into scheduling regions
 #define STAMP(k) { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); long long t1 = clock64(); tph[k] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } }
@@ -394,7 +396,7 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
         pi = npi; chunk = nchunk; cur = nxt; have = nhave;
     }
 #ifdef VAE_PHASE_STAMPS
-    if (a.dbg && lane == 0) { for (int k = 0; k < 6; ++k) a.dbg[(blockIdx.x * 4 + wave) * 6 + k] = tph[k]; }
+    const long long t_loop_end = clock64();
 #endif
 #undef STAMP
 
@@ -427,6 +429,12 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
             unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)v2);
         }
     }
+#ifdef VAE_PHASE_STAMPS
+    if (a.dbg && lane == 0) {
+        tph[7] = clock64() - t_loop_end;
+        for (int k = 0; k < 8; ++k) a.dbg[(blockIdx.x * NWV + wave) * 8 + k] = tph[k];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -457,12 +465,6 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
         itab[it] = it < nitems ? make_int2(((img * Hs + py) * Ws + px) * Cin + q * E16,
                                            ((pix * PATCH_PITCH + q * 16) >> 4) | ((py == th) << 13) | ((px == tw) << 14) | (img << 15))
                                : make_int2(0, 0xffff << 15);
-    }
-
-    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
-        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-    } else {
-        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
     }
 
     const int R = wv0 * 32 + r;
@@ -616,6 +618,11 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
     int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
     const int pstride = WV ? 4 * gridDim.x : gridDim.x;
+    if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
+        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    }
     __syncthreads();                                       // staging table / coefficients published
     load_coefs(0);
     bool have = pi < n_pairs;
