@@ -20,9 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# main stream + three side streams + the communication stream: more than HIP's default of 4 hardware queues, and streams
-# that share a queue serialise (measured: +10 % step time once RCCL's streams exist).  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# main stream + three side streams (+ the communication stream): more than HIP's default of 4 hardware queues, and
+# streams that share a queue serialise (measured with a process group present: 1.46 ms/step at 4 queues, 1.37 at 6..8).
+# Not 8: with the opt-in overlapped exchange (VAE_DP_OVERLAP=1) 8 queues cost +0.6 ms/step.  Set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -187,6 +188,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = step(args.warmup + i)
+    host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps   # host time to enqueue a step (diagnostic: < ms_per_step when the GPU is the limit)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -330,7 +332,7 @@ def main():
         out = {
             "metric": "training samples/sec (VAE step: forward+ELBO+backward+AdamW), synthetic pianoroll",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"VanillaVAE latent_dim={L}, {H}x{H} synthetic pianoroll, batch {B}/GPU"
                                    f"{' (generalised bottleneck 256*(H/16)^2)' if gen else ' (reference-exact 32x32 model)'}",

@@ -118,17 +118,18 @@ def allreduce_gradients(model: VanillaVAE, optimizer=None):
 
 def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool = True, overlap: bool | None = None):
     """One training step on the fused path (train.py:634-656): forward, ELBO, backward, [gradient all-reduce], AdamW.
-    Data parallel with the library communicator (the product path on a multi-GPU node): ``overlap`` puts the decoder
-    bucket's all-reduce on the context's communication stream between the two halves of the backward, so that it runs
-    under the encoder half; the encoder bucket follows in line on the compute stream, directly in front of the AdamW
-    kernel.  ``overlap=False`` issues both buckets as one RCCL group after the backward.  Default: overlap with the
-    library communicator, in line through torch.distributed (whose stream hand-offs cost more than they hide);
-    VAE_DP_OVERLAP=0/1 overrides."""
+    Data parallel (the product path on a multi-GPU node): by default both gradient buckets go out as ONE RCCL group
+    through the library's communicator on the compute stream, between the last backward kernel and the AdamW kernel
+    (3 MB of f32 gradients: measured +15 us per step with a one-rank communicator on MI355X).  ``overlap=True`` puts the
+    decoder bucket's all-reduce on the context's communication stream between the two halves of the backward, under
+    the encoder half, the encoder bucket following in line; measured here that costs more than the ~40 us it can hide
+    (+40..+70 us: a second host call into the backward, two event hand-offs) and falls off a cliff (+0.6 ms) when HIP
+    has 8 hardware queues, so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
     if not _dist_active():
         out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
     else:
         if overlap is None:
-            overlap = os.environ.get("VAE_DP_OVERLAP", "1" if getattr(model, "_want_lib_comm", False) else "0") == "1"
+            overlap = os.environ.get("VAE_DP_OVERLAP", "0") == "1"
         if overlap:
             out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps,
                                                       on_decoder_grads=lambda: _reduce(model, ("decoder",), on_comm_stream=True))
