@@ -20,10 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# main stream + three side streams (+ the communication stream): more than HIP's default of 4 hardware queues, and
-# streams that share a queue serialise (measured with a process group present: 1.46 ms/step at 4 queues, 1.37 at 6..8).
-# Not 8: with the opt-in overlapped exchange (VAE_DP_OVERLAP=1) 8 queues cost +0.6 ms/step.  Set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+# main stream + three side streams (+ the communication stream, + a process group's own): more than HIP's default of 4
+# hardware queues, and streams that share a queue serialise (measured with a process group present: 1.47 ms/step at 4
+# queues, 1.39 at 6..8; without one 4..8 are the same).  Set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -2,7 +2,7 @@
 """Turn rocprofv3 PMC passes of bench.py into profiles/pmc_traffic.json (HBM bytes per launch per bench label).
 
 Usage (on the GPU box, after `bench.py --kernels --dump-order gpurun_out/order.json` and the PMC passes):
-    python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <order.json> <H> <L> <B> <dtype>
+    python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <order.json> <H> <L> <B> <dtype> [--out file.json]
 
 The two passes are separate rocprofv3 runs (`--pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE
 --kernel-trace`, MI355X_MICROARCH.md HBM section).  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests
@@ -20,7 +20,7 @@ def load(d, counter):
 
 
 # label prefix -> regex of the device kernel(s) that label launches first
-KERNEL_OF = [("down_", r"(?<![a-z_])down2?_kernel"), ("up_", r"(?<![a-z_])up2?_kernel"), ("wgrad_kernel", r"(?<![a-z_])wgrad_kernel"),
+KERNEL_OF = [("convT_bwd_fused", r"convt_bwd_fused_kernel"), ("conv_bwd_fused", r"(?<![a-z_])conv_bwd_fused_kernel"), ("down_", r"(?<![a-z_])down2?_kernel"), ("up_", r"(?<![a-z_])up2?_kernel"), ("wgrad_kernel", r"(?<![a-z_])wgrad_kernel"),
              ("convout_fwd", r"convout_fwd"), ("convout_bwd", r"convout_bwd"), ("conv1_fwd", r"conv1_fwd"),
              ("conv1_wgrad", r"conv1_wgrad"), ("dense", r"dense_kernel"), ("decin_fwd", r"decin_fwd"),
              ("decin_wgrad", r"decin_wgrad"), ("fc_wgrad", r"fc_wgrad"), ("fc_dgrad", r"fc_dgrad"), ("pack_weights", r"pack_kernel"),
@@ -54,6 +54,7 @@ def per_label(rows, labels):
 
 def main():
     fdir, wdir, order_json, H, L, B, dtype = sys.argv[1:8]
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
     order = json.load(open(order_json))
     fetch = per_label(load(fdir, "FETCH_SIZE"), order)
     write = per_label(load(wdir, "WRITE_SIZE"), order)
@@ -62,6 +63,9 @@ def main():
         res = json.load(open(path))
     except Exception:
         res = {}
+    suffix = f"|H{H}|L{L}|B{B}|{dtype}"
+    res = {k: v for k, v in res.items() if not k.endswith(suffix)}   # this configuration is re-measured: drop labels that no longer exist
+    # (figures are per device launch: a two-level slab reduction is two launches under one bench label)
     for label in fetch:
         if label not in write or not fetch[label]:
             continue
@@ -69,6 +73,7 @@ def main():
         w = 1024.0 * sum(write[label]) / len(write[label])
         res[f"{label}|H{H}|L{L}|B{B}|{dtype}"] = {"fetch_bytes_x2": f, "write_bytes": w, "traffic_bytes_per_launch": f + w,
                                                  "launches_averaged": len(fetch[label])}
+    path = out_path or path
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path, len(res), "entries")
 

@@ -19,7 +19,7 @@ for l in open(events_txt):
     m = re.match(r"\s+(.+?)\s+calls/step\s+(\d+)\s+([\d.]+) ms/step\s+([\d.]+) GB/s\s+([\d.]+) TF", l)
     if m:
         ev.append((m.group(1), int(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))))
-out = [f"# Round 1 profile summary ({tag}) - bench.py, H={H} L={L} B={B} {dtype}, 1x MI355X", ""]
+out = [f"# Profile summary ({tag}) - bench.py, H={H} L={L} B={B} {dtype}, 1x MI355X", ""]
 out += [f"Step: **{bench['ms_per_step']} ms**, {bench['value']} {bench['unit']}; step_roofline {bench['step_roofline']}.", ""]
 r = bench["roofline"]
 out += ["## Dominant launch (bench.py `roofline`)", "",

@@ -10,7 +10,7 @@ import os as _os
 # The step uses five HIP streams (caller's + three side streams + communication); HIP's default of four hardware
 # queues makes streams share queues and serialise (+10 % step time once RCCL's streams exist).  Read when HIP starts,
 # so it only takes effect if this package is imported before the first HIP call; harmless otherwise.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .types_helpers import EncoderOutput, LossOutput, ModelOutput  # noqa: F401,E402
 

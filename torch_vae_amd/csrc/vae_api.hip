@@ -1,5 +1,7 @@
 // Context and the C ABI (include/vae_step.h) of the VAE step.  The launch sequencing is templated on the storage
 // type and lives in vae_impl.cuh, instantiated by impl_bf16.hip / impl_f16.hip / impl_f32.hip.
+#include <map>
+#include <mutex>
 #include "vae_ctx.h"
 #include "edge_kernels.cuh"
 
@@ -48,14 +50,38 @@ template <typename T> static T* dalloc(vae_ctx* c, size_t n) {
     return reinterpret_cast<T*>(p);
 }
 
+// Side streams and the communication stream are per DEVICE, shared by every context of the process: each extra stream
+// beyond HIP's hardware queues (GPU_MAX_HW_QUEUES) shares a queue with another and serialises with it - a second model
+// in the process (evaluation copy, another batch size) used to slow the first one's step down by up to 3x.  Contexts of
+// one device enqueue in host order, so sharing costs them nothing.  The streams live for the process.
+struct DevStreams { hipStream_t side[vae_ctx::NSIDE]; hipStream_t comm; };
+static DevStreams* device_streams(int side_prio) {
+    static std::mutex mu;
+    static std::map<int, DevStreams*> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find(dev);
+    if (it != pool.end()) return it->second;
+    DevStreams* d = new DevStreams();
+    bool ok = true;
+    for (int i = 0; i < vae_ctx::NSIDE && ok; ++i) ok = hipStreamCreateWithPriority(&d->side[i], hipStreamNonBlocking, side_prio) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { delete d; return nullptr; }
+    pool[dev] = d;
+    return d;
+}
+
 extern "C" void vae_destroy(vae_ctx* c) {
     if (!c) return;
     (void)vae_comm_destroy(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->n_side_ok) {
-        for (int i = 0; i < vae_ctx::NSIDE; ++i) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
+        // (the streams belong to the device pool; work of this context still on them is drained first)
+        for (int i = 0; i < vae_ctx::NSIDE; ++i) { (void)hipStreamSynchronize(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
+        (void)hipStreamSynchronize(c->comm);
         for (int i = 0; i < vae_ctx::NFORK; ++i) (void)hipEventDestroy(c->ev_fork[i]);
-        (void)hipEventDestroy(c->ev_pack); (void)hipStreamDestroy(c->comm); (void)hipEventDestroy(c->ev_comm);
+        (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm);
     }
     delete c;
 }
@@ -138,12 +164,16 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
             int prio_least = 0, prio_greatest = 0, side_prio = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
             if (const char* e = getenv("VAE_SIDE_PRIORITY")) side_prio = !strcmp(e, "low") ? prio_least : !strcmp(e, "high") ? prio_greatest : 0;
-            for (int i = 0; i < vae_ctx::NSIDE && ok; ++i)
-                ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, side_prio) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+            DevStreams* ds = device_streams(side_prio);
+            ok = ds != nullptr;
+            for (int i = 0; i < vae_ctx::NSIDE && ok; ++i) {
+                c->side[i] = ds->side[i];
+                ok = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+            }
             for (int i = 0; i < vae_ctx::NFORK && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) == hipSuccess;
-            if (ok) ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess &&
-                         hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking) == hipSuccess &&
-                         hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) == hipSuccess;
+            if (ok) { c->comm = ds->comm;
+                      ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess &&
+                           hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) == hipSuccess; }
             c->n_side_ok = ok ? 1 : 0;
         }
     }
@@ -427,7 +457,8 @@ extern "C" int vae_profile_report(vae_ctx* c, char* buf, int64_t cap) {
 extern "C" int vae_profile_sequence(vae_ctx* c, char* buf, int64_t cap) {
     if (!c) return vae_set_error("vae_profile_sequence", "null ctx");
     std::string out = "[";
-    for (size_t i = 0; i < c->prof_recs.size(); ++i) out += std::string(i ? "," : "") + "\"" + c->prof_recs[i].name + "\"";
+    for (size_t i = 0; i < c->prof_recs.size(); ++i)
+        for (int k = 0; k < c->prof_recs[i].launches; ++k) out += std::string(out.size() > 1 ? "," : "") + "\"" + c->prof_recs[i].name + "\"";
     out += "]";
     if ((int64_t)out.size() + 1 > cap) return vae_set_error("vae_profile_sequence", "buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);

@@ -101,7 +101,7 @@ struct vae_ctx {
     int use_tr16, use_mfma_convout, use_pipelined, knob_up_per_cu, knob_convout_grid, knob_convout_bwd_grid, knob_down_per_cu, knob_nt_max, knob_pipe_max_cout, knob_ablate_b; long long* dbg_buf; char dbg_tag[32]; int dbg_epi; int64_t ws_bytes;
     std::vector<void*> allocs;
     // per-kernel timing (bench.py roofline): HIP events on the launch stream
-    int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; int side; }; std::vector<ProfRec> prof_recs;
+    int prof; const char* tag; struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes, flops; int side; int launches = 1; }; std::vector<ProfRec> prof_recs;
     hipStream_t cur_stream = nullptr; bool cur_stream_set = false;   // the caller's stream of the call in progress (profiling: tells critical-chain launches from side-stream ones)
 };
 

@@ -138,6 +138,7 @@ static int launch_reduce(const float* slab, int nslab, size_t n, float* out, int
         constexpr size_t kSlot = 16384;     // fixed slot stride: reductions of different sizes must never overlap
         if (n * G > kSlot) return vae_set_error("reduce", "two-level scratch slot too small");
         float* tmp = c->reduce_tmp + (size_t)(c->reduce_slot++ % (c->reduce_tmp_floats / kSlot)) * kSlot;
+        if (ps.idx >= 0) c->prof_recs[ps.idx].launches = 2;   // (vae_profile_sequence lists one entry per device launch)
         hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64), G), dim3(256), 0, st, slab, nslab, (int)n, tmp, 0, 0, 1.f, per);
         LAUNCH_CHECK("reduce_slab_kernel");
         hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, tmp, G, (int)n, out, CA, CB, c->ginv, G);

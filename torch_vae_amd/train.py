@@ -123,8 +123,8 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     (3 MB of f32 gradients: measured +15 us per step with a one-rank communicator on MI355X).  ``overlap=True`` puts the
     decoder bucket's all-reduce on the context's communication stream between the two halves of the backward, under
     the encoder half, the encoder bucket following in line; measured here that costs more than the ~40 us it can hide
-    (+40..+70 us: a second host call into the backward, two event hand-offs) and falls off a cliff (+0.6 ms) when HIP
-    has 8 hardware queues, so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
+    (+40..+70 us: a second host call into the backward, two event hand-offs; +0.6 ms in one configuration of hardware
+    queues), so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
     if not _dist_active():
         out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
     else:
