@@ -47,10 +47,13 @@ class FusedAdamW(torch.optim.Optimizer):
         flat = model.flat_parameters()
         self._m = torch.zeros_like(flat)
         self._v = torch.zeros_like(flat)
+        # one step counter tensor shared by every parameter's state (torch keeps one per parameter and bumps each: 16 host
+        # tensor ops per step); state_dict() shows the same values either way
+        self._step_t = torch.tensor(0.0)
         for g in self.param_groups:
             for p in g["params"]:
                 o, n = model._offs[p._vae_index], model._sizes[p._vae_index]
-                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[o:o + n].view(p.shape),
+                self.state[p] = {"step": self._step_t, "exp_avg": self._m[o:o + n].view(p.shape),
                                  "exp_avg_sq": self._v[o:o + n].view(p.shape)}
 
     def load_state_dict(self, state_dict):
@@ -69,9 +72,12 @@ class FusedAdamW(torch.optim.Optimizer):
                         view.copy_(st[key])
                     st[key] = view
                 step = max(step, int(st.get("step", 0)))
-                st["step"] = torch.tensor(float(step))
                 self.state[p] = st
         self._step = step
+        self._step_t = torch.tensor(float(step))
+        for g in self.param_groups:
+            for p in g["params"]:
+                self.state[p]["step"] = self._step_t
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -79,12 +85,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._bind()
         model = self._model
         gflat = model.flat_grads()
+        views = model._param_grad_views()[1]
         active = []
         for g, rng in zip(self.param_groups, self._ranges):
             grads = [p.grad for p in g["params"]]
             if all(gr is None for gr in grads):
                 continue  # torch skips parameters without gradients
             for p, gr in zip(g["params"], grads):
+                if gr is views[p._vae_index]:
+                    continue              # the fused path's own view of the flat gradient buffer
                 o, n = model._offs[p._vae_index], model._sizes[p._vae_index]
                 if gr is None:
                     raise NotImplementedError("a FusedAdamW group with only some gradients set")
@@ -104,12 +113,10 @@ class FusedAdamW(torch.optim.Optimizer):
             if (g["betas"][1], g["eps"], g["weight_decay"]) != (g0["betas"][1], g0["eps"], g0["weight_decay"]):
                 raise NotImplementedError("groups must share beta2, eps and weight_decay")
         dev = gflat.device
-        with torch.cuda.device(dev):   # launch on the model's device, whatever the caller's current device is
+        with model._device_guard():    # launch on the model's device, whatever the caller's current device is
             _lib.check(_lib.lib().vae_adamw_step(
                 model.flat_parameters().data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n, offs, sizes,
                 lrs, b1s, float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(self.grad_scale),
                 self._step, torch.cuda.current_stream(dev).cuda_stream), "vae_adamw_step")
-        for g, _ in active:
-            for p in g["params"]:
-                self.state[p]["step"] += 1
+        self._step_t += 1
         return loss
