@@ -251,7 +251,7 @@ int pack_weights(vae_ctx* c, const float* params, hipStream_t st) {
         c->packed_for = params;
     }
     ProfScope ps(c, "pack_weights", 0, 0, st);
-    hipLaunchKernelGGL((pack_kernel<T>), dim3(128, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
+    hipLaunchKernelGGL((pack_kernel<T>), dim3((unsigned)c->knob_pack_grid, (unsigned)d.size()), dim3(256), 0, st, c->d_descs);
     LAUNCH_CHECK("pack_kernel");
     return 0;
 }
@@ -391,7 +391,8 @@ int forward_impl(vae_ctx* c, const float* x, int B, const float* params, float* 
     }
     {
         const long P = (long)B * (H / 2) * (H / 2);
-        const int grid = (int)std::min<long>((P + 63) / 64, c->knob_conv1_grid);   // few workgroups: one f64 atomic per channel each
+        // a workgroup covers 64 quads of 4 output pixels per pass; few workgroups: one f64 atomic per channel each
+        const int grid = (int)std::min<long>((P / 4 + 63) / 64, c->knob_conv1_grid);
         ProfScope ps(c, "conv1_fwd", 4.0 * B * H * H + (double)sizeof(T) * 32.0 * P, 2.0 * 9 * 32 * P, st);
         hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, params + c->poff[0], params + c->poff[1],
                            reinterpret_cast<T*>(c->lay[0].y), c->lay[0].stat_f, B, H, H);
