@@ -177,7 +177,8 @@ int vae_profile_sequence(vae_ctx* ctx, char* buf, int64_t capacity);
 int vae_profile_timeline(vae_ctx* ctx, char* buf, int64_t capacity);
 /* Diagnostics: per-wave phase cycle counters of the pipelined conv kernel of one layer.  tag = layer label
  * ("final_layer.0" ...), epi = epilogue kind (0 forward, 1 backward, 2 plain; +16 selects the transposed-conv
- * kernel), out = device buffer of grid*4*6 int64 (NULL switches it off). */
+ * kernel), out = device buffer of grid*waves*8 int64 for the stride-2 conv kernel (6 loop phases + prologue + tail),
+ * grid*4*6 for the transposed-conv kernel (NULL switches it off).  Needs a `make STAMPS=1` build. */
 int vae_debug_stamps(vae_ctx* ctx, const char* tag, int epi, long long* out);
 
 /* Debug / test hooks: copy an internal NHWC tensor to f32 NCHW.  which: 0..7 raw conv output
@@ -191,9 +192,14 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
  *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
  *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
- *   use_fused_wgrad [1]     one pass over (dz, y) for the input AND weight gradient of final_layer.0 / decoder.2 / encoder.1
- *                           (16-bit storage; conv_fused.cuh; 2: decoder side only, 3: encoder.1 only); knob_fused_grid [256] their
- *                           persistent workgroups; use_recomp_dz [0] final_layer.0's dz recomputed from dlogit instead of stored
+ *   use_fused_wgrad [3]     bit 0: one pass over (dz, y) for the input AND weight gradient of final_layer.0 / decoder.2 / encoder.1
+ *                           (16-bit storage; conv_fused.cuh): bit 0 the transposed-conv layers final_layer.0 / decoder.2, bit 1
+ *                           encoder.1; knob_fused_grid [256] their persistent workgroups; use_recomp_dz [0] final_layer.0's dz
+ *                           recomputed from dlogit instead of stored (bit-identical, measured slower);
+ *                           use_raw_wgrad [0] deep weight gradients from operands materialised by the input-gradient kernels
+ *                           (bit-identical, measured 1 % slower)
+ *   knob_down_waves [8]     waves of the wide (128-channel tile) stride-2 conv kernel: 8 = 2x4 wave grid, 4 = 2x2
+ *   knob_lay22_min_nt [4]   wave-grid layouts for output tiles of at least this many 32-channel blocks
  *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with
  *                           what its producer wrote last finds it in L2 / the memory-side cache
@@ -205,7 +211,9 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   knob_wave_nt_max [4]    wave-independent tiles for output tiles of up to this many 32-channel blocks
  *   knob_nt_max [4], knob_up_per_cu [4], knob_down_per_cu [2] (measured flat 1-4), knob_convout_grid [1536], knob_convout_bwd_grid [1536] (persistent workgroups of the output-conv forward / backward kernels: two full rounds of the 768 that fit by LDS beat 2048 by 1 %), knob_pipe_max_cout [256], knob_bwd_per_cu [0],
  *   knob_wgrad_tile [1], knob_wgrad_wide [1], knob_wgrad_wgs [128], knob_wgrad_wide_wgs [128], knob_wgrad_cap_mb [48],
- *   knob_conv1_grid [1024], knob_ablate_b [0]   grid / tile sizing */
+ *   knob_conv1_grid [1024], knob_pack_grid [128], knob_ablate_b [0]   grid / tile sizing
+ *   knob_skip_wgrad [0], knob_ablate_f [0]      ablation diagnostics (skip weight-gradient launches by layer mask / phases
+ *                           of the encoder.1 fused kernel): results are WRONG when set - timing experiments only */
 int vae_set_option(vae_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus
