@@ -6,8 +6,8 @@ from argparse import Namespace
 from torch_vae_amd import _lib
 from torch_vae_amd.models import VanillaVAE
 from torch_vae_amd.train import SyntheticPianorollLoader, build_optimizer
-H, L, B = 128, 16, 256
-model = VanillaVAE(1, L, H, generalised=True, compute_dtype="bf16", max_batch=B).cuda()
+H = int(os.environ.get("VAE_TL_SIZE", "128")); L, B = 16, 256
+model = VanillaVAE(1, L, H, generalised=(H != 32), compute_dtype="bf16", max_batch=B).cuda()
 cfg = Namespace(batch_size_per_gpu=B, world_size=1, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW", scheduler="OneCycle", epochs=1, freeze_encoder=False)
 opt, sched = build_optimizer(cfg, model, steps_per_epoch=100000)
 x = SyntheticPianorollLoader(B, H, 1, device="cuda").batch(0)[0]

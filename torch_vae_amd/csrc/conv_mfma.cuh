@@ -37,6 +37,7 @@ template <typename T> struct ConvArgs {
     long long* dbg;                                                // diagnostic builds only: per-wave phase cycle counters
     BnFuse fuse;                                                   // mode != 0: derive the staging coefficients from batch statistics (pipelined kernels)
     int rev, n_mt;                                                 // walk the M tiles in reverse order (n_mt of them)
+    int xcd;                                                       // gridDim/8 when the persistent kernels renumber their workgroups per XCD (0: off)
     // pipelined kernels: when set, every staged (transformed, storage-rounded) chunk a tile OWNS (its non-halo pixels, N tile 0)
     // is also written here, in the source tensor's layout: the materialised activation / BatchNorm-backward gradient that the
     // deep layers' weight-gradient kernels then read without any staging arithmetic

@@ -103,6 +103,10 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
+    // virtual workgroup id: workgroups are dealt to the 8 XCDs round-robin (XCD = blockIdx % 8); the N tiles of one M tile
+    // and neighbouring M tiles are consecutive ids, so each XCD takes a contiguous range of them and the input patch an
+    // M tile's N tiles share is fetched into ONE L2 instead of two to four (a.xcd = gridDim/8, 0: identity)
+    const int vb = a.xcd ? (int)(blockIdx.x & 7) * a.xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int wm = W22 ? (wave & 1) : wv0, wn = W22 ? (wave >> 1) : 0;   // wave coordinates in the workgroup tile
     const int mrow0 = wm * OROWS;                                         // first tile pixel of this wave
     constexpr int SSTR = WV ? 64 : NTHR;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
     // accumulators start from the conv bias
     float ebv[NTW], esc[NTW], esh[NTW], eis[NTW], exm[NTW];
     {
-        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT + wn * NTW * 32;
+        const int n0w = (vb % ntiles_n) * 32 * NT + wn * NTW * 32;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int n = n0w + nt * 32 + r;
@@ -272,8 +276,8 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
         }
     };
 
-    // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
-    int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
+    // WV: the workgroup keeps its N tile (vb % ntiles_n); its waves take adjacent M tiles
+    int pi = WV ? ((vb / ntiles_n) * 4 + wave) * ntiles_n + vb % ntiles_n : vb, chunk = 0;
     const int pstride = WV ? 4 * gridDim.x : gridDim.x;
     if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
         for (int i = tid; i < Cin; i += NTHR) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
@@ -423,7 +427,7 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
             }
-            const int n0 = (blockIdx.x % ntiles_n) * 32 * NT;
+            const int n0 = (vb % ntiles_n) * 32 * NT;
             double* st_ = a.stat + stat_rep() * 2 * Cout;
             unsafeAtomicAdd(&st_[n0 + tid], (double)v1);
             unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)v2);
@@ -447,6 +451,10 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int stid = WV ? lane : tid, wv0 = WV ? 0 : wave;   // staging thread index; tile-local wave index
+    // virtual workgroup id: workgroups are dealt to the 8 XCDs round-robin (XCD = blockIdx % 8); the N tiles of one M tile
+    // and neighbouring M tiles are consecutive ids, so each XCD takes a contiguous range of them and the input patch an
+    // M tile's N tiles share is fetched into ONE L2 instead of two to four (a.xcd = gridDim/8, 0: identity)
+    const int vb = a.xcd ? (int)(blockIdx.x & 7) * a.xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     constexpr int SSTR = WV ? 64 : 256;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
     const int PH = th + 1, PW = tw + 1, PP = PH * PW, npix = TB * PP, nitems = npix * 4;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
     // one N tile per workgroup for its whole life: epilogue coefficients live in registers
     float ebv[NT], esc[NT], esh[NT], eis[NT], exm[NT];
     {
-        const int n0w = (blockIdx.x % ntiles_n) * 32 * NT;
+        const int n0w = (vb % ntiles_n) * 32 * NT;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0w + nt * 32 + r;
@@ -615,8 +623,8 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
                 for (int i = 0; i < 16; ++i) acc[c][nt][i] = ebv[nt];   // forward accumulators start from the conv bias
         }
     }
-    // WV: the workgroup keeps its N tile (blockIdx.x % ntiles_n); its waves take adjacent M tiles
-    int pi = WV ? ((blockIdx.x / ntiles_n) * 4 + wave) * ntiles_n + blockIdx.x % ntiles_n : blockIdx.x, chunk = 0;
+    // WV: the workgroup keeps its N tile (vb % ntiles_n); its waves take adjacent M tiles
+    int pi = WV ? ((vb / ntiles_n) * 4 + wave) * ntiles_n + vb % ntiles_n : vb, chunk = 0;
     const int pstride = WV ? 4 * gridDim.x : gridDim.x;
     if (a.fuse.mode != BNF_NONE) {   // finalise the input layer's BatchNorm here (workgroup 0 also records it)
         for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(256, ((NT > 1 || (sizeof(T) == 4 && EPI == EPI_BWD)
             float v1 = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }
-            const int n0 = (blockIdx.x % ntiles_n) * 32 * NT;
+            const int n0 = (vb % ntiles_n) * 32 * NT;
             double* st_ = a.stat + stat_rep() * 2 * Cout;
             unsafeAtomicAdd(&st_[n0 + tid], (double)v1);
             unsafeAtomicAdd(&st_[Cout + n0 + tid], (double)v2);

@@ -99,6 +99,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     const int n_wg_pairs = wv ? ((n_mt + 3) / 4) * ntn : n_pairs;    // workgroup-level work items
     int grid = std::min(n_wg_pairs, 256 * ((c->knob_bwd_per_cu > 0 && a.epi != EPI_FWD) ? std::min(per_cu, c->knob_bwd_per_cu) : per_cu));
     grid = std::max(ntn, grid / ntn * ntn);   // a workgroup must stay on one N tile (register-resident statistics)
+    a.xcd = (c->knob_xcd_map && grid % 8 == 0 && (grid / 8) % ntn == 0) ? grid / 8 : 0;   // contiguous id range per XCD (conv_pipe.cuh: vb)
     const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
     const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
     ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
