@@ -68,6 +68,12 @@ int64_t vae_workspace_bytes(const vae_ctx* ctx);
  *   eps [B,L] f32: the torch.randn_like draw of models.py:182; NULL -> generated on device
  *       from the counter-based normal generator (seed, stream 5) that oracle/ restates
  *   train=0 uses running statistics (model.eval(), evaluation.py:42)
+ *   train=2: a training forward whose standard-ELBO backward follows unconditionally (the fused step, train.py:634-650
+ *       as one chain).  The library MAY then leave the output conv, sigmoid and BCE to vae_backward / vae_backward_part,
+ *       where one kernel does that layer's forward and backward in a single pass over its input: xhat, the running
+ *       statistics of final_layer's BatchNorm and the ELBO scalars (through vae_loss_deferred, which must be used
+ *       instead of vae_loss) are then written by the backward, which must be the standard one (use_std = 1, no
+ *       upstream gradient on xhat, no loss scale) and can run once.  x and xhat must stay valid until it has run.
  *   outputs: xhat [B,1,H,W], mu/log_var/z [B,L], all f32. */
 int vae_forward(vae_ctx* ctx, const float* x, int batch, const float* params, float* bn_running,
                 int64_t* num_batches_tracked, const float* eps, uint64_t seed, int train, float* xhat,
@@ -192,6 +198,8 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   use_pipelined [1]       persistent prefetching conv kernels (0: one tile per workgroup)
  *   use_side_stream [1]     weight gradients / weight packing on the context's side streams
  *   use_fused_bn [1]        BatchNorm finalisation inside the consumer kernel's prologue
+ *   use_fused_convout [1]   honour train = 2 (output conv forward + backward as one kernel; 16-bit storage);
+ *                           knob_convout_step_grid [1024] its persistent workgroups (swept 512-4096: 1.328 / 1.323 / 1.334 / 1.341 / 1.354 ms)
  *   use_fused_wgrad [3]     bit 0: one pass over (dz, y) for the input AND weight gradient of final_layer.0 / decoder.2 / encoder.1
  *                           (16-bit storage; conv_fused.cuh): bit 0 the transposed-conv layers final_layer.0 / decoder.2, bit 1
  *                           encoder.1; knob_fused_grid [256] their persistent workgroups; use_recomp_dz [0] final_layer.0's dz

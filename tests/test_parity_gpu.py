@@ -1008,3 +1008,39 @@ def test_materialised_operands_weight_gradients_match(cfg):
             assert rel_l2(res[1][1][n], res[0][1][n]) < 1e-6, (n, rel_l2(res[1][1][n], res[0][1][n]))
         else:
             np.testing.assert_array_equal(res[1][1][n], res[0][1][n], err_msg=n)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_deferred_output_conv_matches_separate_kernels(dtype):
+    """The fused step's forward runs with train = 2: output conv + sigmoid + BCE are left to the backward, where ONE kernel
+    does that layer's forward and backward in a single pass over y7 (convout_step_mfma_kernel).  Same arithmetic element
+    for element as convout_fwd_mfma_kernel + convout_bwd_mfma_kernel: xhat, the ELBO scalars, dz of final_layer's
+    BatchNorm and every gradient must be bit-identical; BatchNorm running statistics too."""
+    from torch_vae_amd import _lib
+    H, L, B = 64, 16, 6
+    p = perturbed_params(L, H, 11, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 5)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 5, 5).reshape(B, L)).float().cuda()
+    res = []
+    for fused in (0, 1):
+        m = make_model(H, L, True, dtype, p, kld_weight=2.0)
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_fused_convout", fused), "set")
+        out3, xhat = m.fused_forward_backward(x, eps=eps)
+        dz7 = torch.empty(B * 32 * H * H, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 15, dz7.data_ptr(), dz7.numel(), torch.cuda.current_stream().cuda_stream), "dbg")
+        res.append((out3.clone(), xhat.clone(), dz7, m.flat_grads().clone(), m._bnflat.clone()))
+        if fused:     # the deferred forward can be differentiated once, and only through the standard ELBO
+            assert _lib.lib().vae_backward(m._ctx.handle, x.data_ptr(), m._flat.data_ptr(), m._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
+                                           2.0, 1, torch.cuda.current_stream().cuda_stream) != 0
+    (o0, x0, d0, g0, b0), (o1, x1, d1, g1, b1) = res
+    assert torch.equal(x0, x1) and torch.equal(o0, o1)
+    assert torch.equal(d0, d1)
+    assert torch.equal(b0, b1)
+    from torch_vae_amd._lib import PARAM_NAMES
+    offs, sizes = m._offs, m._sizes
+    bad = {}
+    for n, o, sz in zip(PARAM_NAMES, offs, sizes):
+        if not torch.equal(g0[o:o + sz], g1[o:o + sz]):
+            bad[n] = float((g0[o:o + sz] - g1[o:o + sz]).norm() / g0[o:o + sz].norm())
+    report(test="deferred_output_conv", dtype=dtype, differing=bad)
+    assert not bad, bad

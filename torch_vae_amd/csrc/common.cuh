@@ -184,7 +184,8 @@ struct BnFuse {
 };
 enum { BNF_NONE = 0, BNF_FWD = 1, BNF_BWD = 2 };
 
-__device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool writer, float& k0, float& k1, float& k2) {
+__device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool writer, float& k0, float& k1, float& k2,
+                                                 float* invstd_out = nullptr, float* xm_out = nullptr) {
     const int C = f.C;
     if (f.mode == BNF_FWD) {
         const double mean = stat_sum(f.stat, C, c) / f.count;
@@ -193,6 +194,7 @@ __device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool wr
         const double invstd = 1.0 / sqrt(var + (double)f.eps);
         const double sc = (double)f.gamma[c] * invstd;
         k0 = (float)sc; k1 = 0.f; k2 = (float)((double)f.beta[c] - mean * sc);
+        if (invstd_out) { *invstd_out = (float)invstd; *xm_out = (float)(-mean * invstd); }   // (= block[LC_INVSTD], block[LC_XM])
         if (writer) {
             f.block[LC_SC * C + c] = k0; f.block[LC_ZERO * C + c] = 0.f; f.block[LC_SH * C + c] = k2;
             f.block[LC_INVSTD * C + c] = (float)invstd; f.block[LC_XM * C + c] = (float)(-mean * invstd);

@@ -942,10 +942,12 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
             for (int i = 0; i < 16; ++i) {
                 const int pix = (2 * wave + mb) * 32 + acc_row(i, lane);
                 T* cell = reinterpret_cast<T*>(ytile + pix * PITCH) + r;
-                const float yv = (float)(*cell), z = yv * sc + sh;
+                // (explicit fused multiply-adds: convout_bwd_mfma_kernel and convout_step_mfma_kernel must round alike, and
+                //  left to the compiler the contraction of these expressions came out differently in the two kernels)
+                const float yv = (float)(*cell), z = __builtin_fmaf(yv, sc, sh);
                 const float dzv = (float)(T)(z > 0.f ? acca[mb][i] : acca[mb][i] * a.slope);
                 *cell = (T)dzv;
-                s1 += dzv; s2 += dzv * (yv * is + xm);
+                s1 += dzv; s2 = __builtin_fmaf(dzv, __builtin_fmaf(yv, is, xm), s2);
             }
         }
         // the wave re-reads only its own 64 pixels (in-order LDS within a wave): 4 KiB = 4 chunks per lane
@@ -975,6 +977,232 @@ __global__ __launch_bounds__(256, 2) void convout_bwd_mfma_kernel(ConvOutBwdMfma
     for (int j = tid; j < 288; j += 256) a.slab[(size_t)blockIdx.x * 288 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
     if (tid < 64) unsafeAtomicAdd(&a.stat[stat_rep() * 64 + tid], (double)(red[0][288 + tid] + red[1][288 + tid] + red[2][288 + tid] + red[3][288 + tid]));
     if (tid == 64) unsafeAtomicAdd(a.dbias + stat_rep() * 8, (double)(red[0][352] + red[1][352] + red[2][352] + red[3][352]));
+}
+
+// ---------------------------------------------------------------------------
+// Output conv forward AND backward in one pass over y7 (16-bit modes, the fused training step only: forward with
+// train = 2 leaves the output conv to the backward).  Per 8x32 tile: the (8+4)x(32+4) patch of a = LeakyReLU(BN(y)) is
+// staged once and feeds (1) the per-pixel tap products of the forward (logits on the tile + 1-pixel halo -> sigmoid,
+// BCE, xhat, dlogit), (2) the input gradient dA = dl (*) w and (3) the weight gradient a^T dl - y7 is read once instead
+// of twice (x1.69 halo instead of x1.33 + x1.0) and dlogit never goes to HBM.  Same arithmetic, element for element,
+// as convout_fwd_mfma_kernel followed by convout_bwd_mfma_kernel (tests/test_parity_gpu.py checks bit-identity).
+template <typename T> struct ConvOutStepArgs {
+    const T* yf; const float* wt; const float* bias; const float* target;
+    float* xhat; double* accum;                 // accum[rep*8 + 0] += BCE sum, [rep*8 + 2] += sum of dlogit (bias gradient)
+    T* dz; float* slab; double* stat;           // stat: sum dz | sum dz*xhat7 of final_layer's BatchNorm (replicated)
+    int B, H, W, n_tiles; float inv_n, slope, gmul;
+    BnFuse fuse;                                // final_layer BatchNorm finalised in the prologue (forward mode)
+    int rev;
+};
+
+static inline size_t convout_step_lds() { return 448 * 80 + 8 * 32 * 80 + 448 * 9 * 4 + (10 * 34 + 8) * 4 + 4 * (32 * 9 + 64 + 2) * 4 + 128 * 4; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepArgs<T> a) {
+    typedef typename H16<T>::v8 T8;
+    constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4, NP = PH * PW, NPAD = 448, PITCH = 80, NCHK = NP * 4, MAXI = 7;
+    constexpr int DH = TH + 2, DW = TW + 2, NDL = DH * DW;
+    constexpr int RED = 32 * 9 + 64 + 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // convout_step_lds() bytes (> the 64 KB static limit)
+    char* atile = smem;                                                    // a = LeakyReLU(BN(y)) on the patch
+    char* ytile = atile + NPAD * PITCH;                                    // raw y of the tile, dz in place
+    float* part = reinterpret_cast<float*>(ytile + TH * TW * PITCH);       // [NPAD][9]
+    float* dl_s = part + NPAD * 9;                                         // [NDL + 6]
+    float (*red)[RED] = reinterpret_cast<float (*)[RED]>(dl_s + NDL + 8);  // [4][RED]
+    float* cf = reinterpret_cast<float*>(red) + 4 * RED;                   // scale | shift | invstd | -mean*invstd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    if (tid < 32) { float k1; bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], k1, cf[32 + tid], &cf[64 + tid], &cf[96 + tid]); }
+    for (int i = tid; i < (NPAD - NP) * PITCH / 16; i += 256) *reinterpret_cast<f32x4*>(atile + NP * PITCH + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag<T> wf[2];       // forward: B[k = channel][col = tap r]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[ks].v[j] = (T)(r < 9 ? a.wt[r * 32 + ks * 16 + 8 * h + j] : 0.f);
+    Frag<T> wfrag;       // input gradient: B[k = tap][col = channel r]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int t = 8 * h + j; wfrag.v[j] = (T)(t < 9 ? a.wt[t * 32 + r] : 0.f); }
+    const float bo = a.bias[0], gs = a.gmul;
+    float bsum = 0.f, s1 = 0.f, s2 = 0.f, sdl = 0.f;
+    f32x16 accw;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accw[i] = 0.f;
+
+    auto tile_origin = [&](int tile_, int& b, int& y0, int& x0) {
+        const int tile = a.rev ? a.n_tiles - 1 - tile_ : tile_;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y); y0 = ty * TH; x0 = tx * TW;
+    };
+    T8 pre[MAXI]; int ok[MAXI]; float pretg[2]; int tgok[2];
+    auto prefetch = [&](int tile) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, ry = i / DW, rx = i - ry * DW, gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+            tgok[u] = i < NDL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pretg[u] = a.target[tgok[u] ? ((size_t)b * a.H + gy) * a.W + gx : 0];
+        }
+        const int base = ((b * a.H + y0 - 2) * a.W + x0 - 2) * 32 + (tid & 3) * 8;
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int id = tid + 256 * u, pix = id >> 2;
+            const int py = pix / PW, px = pix - py * PW, gy = y0 - 2 + py, gx = x0 - 2 + px;
+            ok[u] = id < NCHK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const uint32_t g = ok[u] ? (uint32_t)(base + (py * a.W + px) * 32) * 2u : 0u;   // byte offset (< 4 GiB: host check)
+            pre[u] = *reinterpret_cast<const T8*>(reinterpret_cast<const char*>(a.yf) + g);
+        }
+    };
+    __syncthreads();                     // cf published
+    f32x2 kc[4], kh[4];                  // this thread's 8 staging channels: scale / shift pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        kc[e] = f32x2{cf[(tid & 3) * 8 + 2 * e], cf[(tid & 3) * 8 + 2 * e + 1]};
+        kh[e] = f32x2{cf[32 + (tid & 3) * 8 + 2 * e], cf[32 + (tid & 3) * 8 + 2 * e + 1]};
+    }
+    const float sc = cf[r], sh = cf[32 + r], is = cf[64 + r], xm = cf[96 + r];   // epilogue: channel r
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) prefetch(tile);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        int b, y0, x0; tile_origin(tile, b, y0, x0);
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int id = tid + 256 * u, pix = id >> 2;
+            T8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 z = f32x2{(float)pre[u][2 * e], (float)pre[u][2 * e + 1]} * kc[e] + kh[e];
+                const f32x2 zs = z * a.slope;
+                z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+                o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
+            }
+            if (!ok[u]) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (id < NCHK) {
+                *reinterpret_cast<T8*>(atile + pix * PITCH + (id & 3) * 16) = o;
+                const int py = pix / PW, px = pix - py * PW;
+                if (py >= 2 && py < TH + 2 && px >= 2 && px < TW + 2)     // the tile itself: raw y for the epilogue
+                    *reinterpret_cast<T8*>(ytile + ((py - 2) * TW + px - 2) * PITCH + (id & 3) * 16) = pre[u];
+            }
+        }
+        const float tg0 = pretg[0], tg1 = pretg[1]; const int tk0 = tgok[0], tk1 = tgok[1];
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.n_tiles) prefetch(tile + gridDim.x);   // in flight during everything below
+        // ---- forward tap products: 14 row blocks of 32 patch pixels
+        for (int mb = wave; mb < NPAD / 32; mb += 4) {
+            const int row0 = mb * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> af = load_frag(reinterpret_cast<const T*>(atile + (row0 + r) * PITCH + ks * 32) + h * 8);
+                mma(acc, af, wf[ks]);
+            }
+            if (r < 9) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) part[(row0 + acc_row(i, lane)) * 9 + r] = acc[i];
+            }
+        }
+        __syncthreads();
+        // ---- logits, sigmoid, BCE and dlogit on the tile + 1-pixel halo (340 pixels)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u;
+            if (i < NDL) {
+                const int ry = i / DW, rx = i - ry * DW;
+                float logit = bo;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) logit += part[((ry + t / 3) * PW + rx + t % 3) * 9 + t];
+                const float tg = u ? tg1 : tg0;
+                const float xh = 1.f / (1.f + expf(-logit));
+                const float om = xh * (1.f - xh);
+                const float dlv = (xh - tg) / fmaxf(om, 1e-12f) * om * a.inv_n;
+                const float dl = (u ? tk1 : tk0) ? dlv * gs : 0.f;
+                dl_s[i] = dl;
+                if (ry >= 1 && ry <= TH && rx >= 1 && rx <= TW) {   // the tile itself
+                    const float l1 = fmaxf(logf(xh), -100.f), l0 = fmaxf(logf(1.f - xh), -100.f);
+                    bsum += -(tg * l1 + (1.f - tg) * l0);
+                    a.xhat[((size_t)b * a.H + y0 + ry - 1) * a.W + x0 + rx - 1] = xh;
+                    sdl += dl;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dA: 2 blocks of 32 pixels per wave (tile rows 2*wave, 2*wave+1)
+        f32x16 acca[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acca[mb][i] = 0.f;
+            const int ly = 2 * wave + mb, lx = r;
+            Frag<T> af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 8 * h + j, tt = t < 9 ? t : 0;
+                const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
+                af.v[j] = (T)(t < 9 ? v : 0.f);
+            }
+            mma(acca[mb], af, wfrag);
+        }
+        // ---- dW: K = the wave's 64 pixels, A = a^T (k-major via tr16 from the staged patch), B = dl taps
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k0 = wave * 64 + ks * 16 + 8 * (g4 >> 1) + q;            // tile pixel; k0 + 4 is in the same tile row
+            const int row = ((k0 >> 5) + 2) * PW + (k0 & 31) + 2;
+            const int col = (16 * (g4 & 1) + 4 * p) * 2;
+            Frag<T> afr = frag_tr16<T>(atile + row * PITCH + col, atile + (row + 4) * PITCH + col);
+            Frag<T> bfr;
+            const int tt = r < 9 ? r : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pix = wave * 64 + ks * 16 + 8 * h + j, ly = pix >> 5, lx = pix & 31;
+                const float v = dl_s[(ly - tt / 3 + 2) * DW + (lx - tt % 3 + 2)];
+                bfr.v[j] = (T)(r < 9 ? v : 0.f);
+            }
+            mma(accw, afr, bfr);
+        }
+        // ---- epilogue: dz = dA * leaky'(z) written in place over this wave's own y rows
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pix = (2 * wave + mb) * 32 + acc_row(i, lane);
+                T* cell = reinterpret_cast<T*>(ytile + pix * PITCH) + r;
+                // (explicit fused multiply-adds: convout_bwd_mfma_kernel and convout_step_mfma_kernel must round alike, and
+                //  left to the compiler the contraction of these expressions came out differently in the two kernels)
+                const float yv = (float)(*cell), z = __builtin_fmaf(yv, sc, sh);
+                const float dzv = (float)(T)(z > 0.f ? acca[mb][i] : acca[mb][i] * a.slope);
+                *cell = (T)dzv;
+                s1 += dzv; s2 = __builtin_fmaf(dzv, __builtin_fmaf(yv, is, xm), s2);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave re-reads only its own 64 pixels
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;
+            const T8 v = *reinterpret_cast<const T8*>(ytile + pix * PITCH + qq * 16);
+            const size_t g = (((size_t)b * a.H + y0 + (pix >> 5)) * a.W + x0 + (pix & 31)) * 32 + qq * 8;
+            *reinterpret_cast<T8*>(a.dz + g) = v;
+        }
+    }
+
+    // ---- workgroup reductions: dW (rows = channel, lanes 0..8 = tap), statistics, sum of dlogit, BCE sum
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    sdl = wave_sum(sdl); bsum = wave_sum(bsum);
+    __syncthreads();
+    if (r < 9) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][r * 32 + acc_row(i, lane)] = accw[i];
+    }
+    if (h == 0) { red[wave][288 + r] = s1; red[wave][320 + r] = s2; }
+    if (lane == 0) { red[wave][352] = sdl; red[wave][353] = bsum; }
+    __syncthreads();
+    for (int j = tid; j < 288; j += 256) a.slab[(size_t)blockIdx.x * 288 + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (tid < 64) unsafeAtomicAdd(&a.stat[stat_rep() * 64 + tid], (double)(red[0][288 + tid] + red[1][288 + tid] + red[2][288 + tid] + red[3][288 + tid]));
+    if (tid == 64) unsafeAtomicAdd(&a.accum[stat_rep() * 8 + 2], (double)(red[0][352] + red[1][352] + red[2][352] + red[3][352]));
+    if (tid == 65) unsafeAtomicAdd(&a.accum[stat_rep() * 8 + 0], (double)(red[0][353] + red[1][353] + red[2][353] + red[3][353]));
 }
 
 // ---------------------------------------------------------------------------

@@ -221,6 +221,8 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
     if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value == 1 ? 3 : (value == 2 ? 1 : (value == 3 ? 2 : 0)); return 0; }   // 1 all, 2 decoder side only, 3 encoder.1 only
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
+    if (!strcmp(name, "use_fused_convout")) { c->use_fused_convout = value; return 0; }
+    if (!strcmp(name, "knob_convout_step_grid")) { c->knob_convout_step_grid = value > 0 ? value : 1; return 0; }
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }
     if (!strcmp(name, "knob_skip_wgrad")) { c->knob_skip_wgrad = value; return 0; }
     if (!strcmp(name, "use_raw_wgrad")) { c->use_raw_wgrad = value; return 0; }
@@ -318,6 +320,7 @@ extern "C" int vae_decode(vae_ctx* c, const float* z, int B, const float* params
 
 extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
     if (!c || !c->B) return vae_set_error("vae_loss", "no forward");
+    if (c->convout_pending) return vae_set_error("vae_loss", "the forward ran with train = 2: the ELBO is produced by the backward (use vae_loss_deferred)");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->accum, out3,
                        1.0 / ((double)c->B * c->H * c->H), 1.0 / (double)c->B, kld_weight, STAT_R);
     LAUNCH_CHECK("loss_finalize_kernel");
@@ -330,6 +333,7 @@ extern "C" int vae_loss(vae_ctx* c, float kld_weight, float* out3, vae_stream_t 
 extern "C" int vae_loss_deferred(vae_ctx* c, float kld_weight, float* out3, vae_stream_t stream) {
     if (!c || !c->B) return vae_set_error("vae_loss_deferred", "no forward");
     if (!c->trained) return vae_set_error("vae_loss_deferred", "needs a train-mode forward (a backward must follow)");
+    if (c->convout_pending) { c->loss_out3 = out3; c->loss_kw = kld_weight; return 0; }   // finalised by the backward, after the fused output-conv kernel
     SideFork f = (c->knob_lean & 4) ? fork_side(c, (hipStream_t)stream) : SideFork{(hipStream_t)stream, c->slab, 0};
     if (f.rc) return f.rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, f.st, c->accum, out3,

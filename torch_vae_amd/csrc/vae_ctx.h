@@ -91,6 +91,12 @@ struct vae_ctx {
     int use_raw_wgrad = 0;
     int knob_skip_wgrad = 0;  // diagnostics: bit i skips the separate weight-gradient launch of BN layer i (results wrong, timing only)
     int knob_ablate_f = 0;   // diagnostics: phase ablation of conv_bwd_fused_kernel (timing only)
+    // use_fused_convout: a forward with train = 2 (the fused training step) leaves the output conv, sigmoid and BCE to the
+    // backward, where ONE kernel does forward and backward of that layer in one pass over y7 (conv_mfma.cuh:
+    // convout_step_mfma_kernel).  convout_pending: such a forward is waiting for its backward; pending_f7: the BatchNorm
+    // finalisation that kernel's prologue performs; loss_out3 / loss_kw: where vae_loss_deferred wants the ELBO scalars.
+    int use_fused_convout = 1, convout_pending = 0, dlogit_valid = 0, knob_convout_step_grid = 1024;
+    BnFuse pending_f7; float* loss_out3 = nullptr; float loss_kw = 0.f;
     int use_fused_wgrad = 3, knob_fused_grid = 256, use_recomp_dz = 0;   // use_fused_wgrad: bit 0 decoder (ConvT) kernels, bit 1 encoder.1 kernel
     // f16 storage: the backward runs on gradients multiplied by gmul (a power of two chosen per forward so that the stored
     // dz stay inside the f16 range: the BCE mean makes them O(1/(B*H*W))); every parameter gradient is written times ginv.

@@ -346,6 +346,12 @@ int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* b
         const bool mfma_out = sizeof(T) == 2 && c->use_mfma_convout && 64.0 * B * H * H < 4294967296.0;   // 32-bit byte offsets
         BnFuse f7;
         if (input_bn_fwd(c, 7, params, bn_running, nbt, train, mfma_out, &f7, st)) return -1;
+        c->convout_pending = 0; c->loss_out3 = nullptr; c->dlogit_valid = 1;
+        if (train == 2 && mfma_out && c->use_fused_convout && c->use_fused_bn && !c->use_recomp_dz && f7.mode == BNF_FWD && H % 32 == 0) {
+            // fused training step: forward AND backward of this layer run as one kernel at the start of the backward
+            c->pending_f7 = f7; c->convout_pending = 1; c->dlogit_valid = 0;
+            return 0;
+        }
         ProfScope ps(c, "convout_fwd+bce", ((double)sizeof(T) * 32 + 12.0) * B * H * H, 2.0 * 9 * 32 * B * H * H, st);
         bool launched = false;
         if constexpr (sizeof(T) == 2) {
@@ -554,6 +560,9 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
     }
     c->bwd_dirty = 1;
     const float* dl_src = c->dlogit; const float* dl_scale = gscale;
+    const bool step7 = c->convout_pending != 0;
+    if (step7 && (g_xhat || gscale || !add_kl)) return vae_set_error("vae_backward", "the forward ran with train = 2: only the standard ELBO backward (no upstream gradient on xhat, no loss scale) can follow");
+    if (!step7 && add_kl && !c->dlogit_valid) return vae_set_error("vae_backward", "this forward's output-conv gradient was already consumed (train = 2 forwards can be differentiated once)");
     if (g_xhat || !add_kl) {
         // explicit upstream gradient on xhat (plus, when add_kl, the fused standard-ELBO term)
         const long n = (long)B * H * H;
@@ -575,11 +584,26 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         const long P = (long)B * H * H;
         int grid = (int)std::min<long>((P + 63) / 64, 1024);
         const bool will_recomp = sizeof(T) == 2 && c->use_mfma_convout && c->use_recomp_dz && convt_fused_ok<T>(c, 7);
-        ProfScope ps(c, will_recomp ? "convout_bwd(statistics+wgrad, dz not stored)" : "convout_bwd(dgrad+wgrad+bn prologue)",
-                     ((double)sizeof(T) * (will_recomp ? 32 : 64) + 4.0) * P, 3.0 * 2 * 9 * 32 * P, st);
+        ProfScope ps(c, step7 ? "convout_step(fwd+bce+dgrad+wgrad)" : will_recomp ? "convout_bwd(statistics+wgrad, dz not stored)" : "convout_bwd(dgrad+wgrad+bn prologue)",
+                     ((double)sizeof(T) * (will_recomp ? 32 : 64) + (step7 ? 8.0 : 4.0)) * P, (step7 ? 4.0 : 3.0) * 2 * 9 * 32 * P, st);
         bool launched = false;
         if constexpr (sizeof(T) == 2) {
-            if (c->use_mfma_convout) {
+            if (step7) {
+                ConvOutStepArgs<T> m; m.fuse = c->pending_f7; m.rev = (c->knob_rev >> 1) & 1;
+                m.yf = reinterpret_cast<const T*>(c->lay[7].y); m.wt = c->wout_t; m.bias = params + c->poff[39]; m.target = c->x;
+                m.xhat = c->xhat; m.accum = c->accum; m.dz = reinterpret_cast<T*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat;
+                m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
+                m.inv_n = (float)(1.0 / ((double)B * H * H)); m.slope = kSlope; m.gmul = c->gmul;
+                grid = std::min(m.n_tiles, c->knob_convout_step_grid);   // 512 resident (2 per CU by LDS): two full rounds
+                const size_t lds = convout_step_lds();
+                if (set_lds(convout_step_mfma_kernel<T>, lds)) return -1;
+                hipLaunchKernelGGL((convout_step_mfma_kernel<T>), dim3(grid), dim3(256), lds, st, m);
+                launched = true;
+                c->convout_pending = 0;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (!launched && c->use_mfma_convout) {
                 // final_layer.0's gradient kernel can recompute dz from dlogit: then this pass only produces the statistics and
                 // the output conv's weight gradient, and the full-resolution 32-channel dz never goes to HBM
                 recomp7 = c->use_recomp_dz && convt_fused_ok<T>(c, 7);
@@ -602,6 +626,12 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
         if (launch_reduce(f.slab, cgrid, 288, grads + c->poff[38], 1, 32, f.st, c)) return -1;
         hipLaunchKernelGGL(accum_to_f32_kernel, dim3(1), dim3(64), 0, f.st, c->accum + 2, grads + c->poff[39], c->ginv);
         LAUNCH_CHECK("accum_to_f32_kernel");
+        if (step7 && c->loss_out3) {   // the ELBO scalars vae_loss_deferred asked for: the BCE sum exists only now
+            hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, f.st, c->accum, c->loss_out3,
+                               1.0 / ((double)B * H * H), 1.0 / (double)B, c->loss_kw, STAT_R);
+            LAUNCH_CHECK("loss_finalize_kernel");
+            c->loss_out3 = nullptr;
+        }
     }
     // decoder stack: ConvTranspose2d layers 7 (final_layer.0), 6, 5, 4
     for (int i = 7; i >= 4; --i) {

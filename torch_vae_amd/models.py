@@ -395,7 +395,7 @@ class VanillaVAE(nn.Module):
         if x.device != self._flat.device:
             raise RuntimeError("input and model are on different devices")
 
-    def _run_forward(self, x: Tensor, eps: Tensor | None, train: bool, want_pre: bool | None = None):
+    def _run_forward(self, x: Tensor, eps: Tensor | None, train: bool, want_pre: bool | None = None, defer_output: bool = False):
         self._check_input(x)
         x = x.detach().contiguous().float()
         B, L, dev = x.shape[0], self.latent_dim, x.device
@@ -415,7 +415,7 @@ class VanillaVAE(nn.Module):
         with self._device_guard():
             _lib.check(_lib.lib().vae_forward(
                 ctx.handle, x.data_ptr(), B, self._flat.data_ptr(), self._bnflat.data_ptr(), self._nbt.data_ptr(),
-                _lib.ptr(eps), seed, int(train), xhat.data_ptr(), mu.data_ptr(),
+                _lib.ptr(eps), seed, (2 if (train and defer_output) else int(train)), xhat.data_ptr(), mu.data_ptr(),
                 lv.data_ptr(), z.data_ptr(), self._stream()), "vae_forward")
             if want_pre is None:
                 want_pre = self.materialize_pre_latents
@@ -570,7 +570,9 @@ class VanillaVAE(nn.Module):
         self._require_device()
         if eps is None and not use_device_eps:
             eps = torch.randn(x.shape[0], self.latent_dim, device=x.device, dtype=torch.float32)
-        xhat, mu, lv, z, _ = self._run_forward(x, eps, train=True, want_pre=False)
+        # train = 2: the library may leave the output conv / sigmoid / BCE to the backward (one kernel for the layer's
+        # forward and backward): xhat and the ELBO scalars are then written by the backward call below
+        xhat, mu, lv, z, _ = self._run_forward(x, eps, train=True, want_pre=False, defer_output=True)
         out3 = torch.empty(3, device=x.device, dtype=torch.float32)
         # the ELBO scalars are only read after the step: finalised beside the backward (joined by it), not in front of it
         with self._device_guard():
