@@ -75,7 +75,9 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     // tile organisation: 2x2 wave grid over a 128-pixel workgroup tile (wide down tiles: halves the weight-fragment
     // traffic), wave-independent 32-pixel tiles (no workgroup barrier in the loop), or one row of waves per workgroup tile
-    const bool lay22 = is_down && NT >= 2 && NT >= c->knob_lay22_min_nt;   // (f32: NT is 2, used by the exact-arithmetic tests)
+    // (16-bit storage only: f32 keeps the row-of-waves tile.  NT = 2 - encoder.1's forward - measured 47 vs 52 us against the
+    //  wave-independent tiles)
+    const bool lay22 = is_down && sizeof(T) == 2 && NT >= 2 && NT >= c->knob_lay22_min_nt;
     const bool lay24 = lay22 && NT == 4 && sizeof(T) == 2 && c->knob_down_waves == 8;    // eight waves: 2 x 4 grid
     const bool wv = sizeof(T) == 2 && !lay22 && NT <= c->knob_wave_nt_max;
     Tiling t = make_tiling(a.Hs, a.Ws, wv ? 32 : 128);
