@@ -207,6 +207,8 @@ int vae_selftest_tr16(vae_stream_t stream);
  *                           use_raw_wgrad [0] deep weight gradients from operands materialised by the input-gradient kernels
  *                           (bit-identical, measured 1 % slower)
  *   knob_down_waves [8]     waves of the wide (128-channel tile) stride-2 conv kernel: 8 = 2x4 wave grid, 4 = 2x2
+ *   knob_up_nt_max [1]      output channels per workgroup tile of the transposed-conv kernels in 32-channel blocks (1: more, smaller
+ *                           workgroups at two waves per SIMD; 2 = one wave per SIMD measured 2.5 % slower on the step)
  *   knob_lay22_min_nt [2]   wave-grid layouts (16-bit storage) for output tiles of at least this many 32-channel blocks
  *   knob_rev [4]            reverse tile walk (bit 0 output-conv forward, 1 output-conv backward, 2 backward conv kernels,
  *                           3 weight-gradient kernels, 4 forward conv kernels, 5 alternate per launch): a consumer that starts with

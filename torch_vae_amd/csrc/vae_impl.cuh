@@ -72,6 +72,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     int NT = std::min(c->knob_nt_max, a.Cout / 32);
     NT = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
     if (!is_down || sizeof(T) == 4) NT = std::min(NT, 2);
+    if (!is_down) NT = std::min(NT, c->knob_up_nt_max);
     if (!is_down && (a.epi == EPI_BWD || sizeof(T) == 4)) NT = 1;
     // tile organisation: 2x2 wave grid over a 128-pixel workgroup tile (wide down tiles: halves the weight-fragment
     // traffic), wave-independent 32-pixel tiles (no workgroup barrier in the loop), or one row of waves per workgroup tile
