@@ -206,7 +206,8 @@ int vae_selftest_tr16(vae_stream_t stream);
  *                           recomputed from dlogit instead of stored (bit-identical, measured slower);
  *                           use_raw_wgrad [0] deep weight gradients from operands materialised by the input-gradient kernels
  *                           (bit-identical, measured 1 % slower)
- *   knob_down_waves [8]     waves of the wide (128-channel tile) stride-2 conv kernel: 8 = 2x4 wave grid, 4 = 2x2
+ *   knob_down_waves [8]     waves of the wide stride-2 conv kernels: 8 = 2x4 wave grid on 128-channel tiles and (knob_lay42 [1]) 4x2 on
+ *                           64-channel tiles, 4 = 2x2
  *   knob_up_nt_max [1]      output channels per workgroup tile of the transposed-conv kernels in 32-channel blocks (1: more, smaller
  *                           workgroups at two waves per SIMD; 2 = one wave per SIMD measured 2.5 % slower on the step)
  *   knob_lay22_min_nt [2]   wave-grid layouts (16-bit storage) for output tiles of at least this many 32-channel blocks

@@ -88,13 +88,14 @@ __device__ __forceinline__ TileGeo decode_pair(const ConvArgs<T>& a, int pi, int
 // SIMD, so one wave's staging / epilogue VALU and its waits run under the other's MFMAs (the SQ counters of the
 // 4-wave layout: matrix pipe 28 %, VALU 28 %, waiting 38 % of the cycles of the single wave per SIMD).
 template <typename T, int NT, int EPI, bool WV, int LAY = 0>
-__global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
+__global__ __launch_bounds__((LAY >= 2 ? 512 : 256), ((NT > 1 || LAY >= 2) ? 1 : 2)) void down2_kernel(ConvArgs<T> a, int n_pairs, int ntiles_n) {
     constexpr bool TWO_SRC = EPI != EPI_FWD;
-    constexpr bool W22 = LAY >= 1;                       // waves form a 2 x WN grid over the workgroup tile
-    constexpr int NWV = LAY == 2 ? 8 : 4, NTHR = 64 * NWV, WN = LAY == 2 ? 4 : (LAY == 1 ? 2 : 1);
+    constexpr bool W22 = LAY >= 1;                       // waves form a WM x WN grid over the workgroup tile (wave = wm + WM * wn)
+    // LAY = 3: eight waves as 4 x 2 (32 pixels x 32 channels each) for 64-channel tiles (NT = 2)
+    constexpr int NWV = LAY >= 2 ? 8 : 4, NTHR = 64 * NWV, WN = LAY == 2 ? 4 : (LAY == 1 || LAY == 3 ? 2 : 1), WM = W22 ? NWV / WN : 1;
     static_assert(!W22 || (!WV && NT % WN == 0), "wave-grid layouts: workgroup tiles, NT a multiple of the grid's N width");
-    constexpr int MTW = W22 ? 2 : 1, NTW = NT / WN, OROWS = 32 * MTW;   // per wave: M sub-tiles, N sub-tiles, out-tile rows
-    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = LAY == 2 ? 5 : 10;
+    constexpr int MTW = W22 ? 4 / WM : 1, NTW = NT / WN, OROWS = 32 * MTW;   // per wave: M sub-tiles, N sub-tiles, out-tile rows
+    constexpr int CK = 64 / sizeof(T), KS = CK / 16, E16 = 16 / sizeof(T), MAXI = LAY >= 2 ? 5 : 10;
     constexpr int OROW = 32 * NTW * sizeof(T), OPITCH = OROW + 16, OCH = OROW / 16;  // out-tile row bytes / chunks
     constexpr int OPL = OROWS * OCH / 64;                                            // out chunks per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
     // and neighbouring M tiles are consecutive ids, so each XCD takes a contiguous range of them and the input patch an
     // M tile's N tiles share is fetched into ONE L2 instead of two to four (a.xcd = gridDim/8, 0: identity)
     const int vb = a.xcd ? (int)(blockIdx.x & 7) * a.xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int wm = W22 ? (wave & 1) : wv0, wn = W22 ? (wave >> 1) : 0;   // wave coordinates in the workgroup tile
+    const int wm = W22 ? (wave % WM) : wv0, wn = W22 ? (wave / WM) : 0;   // wave coordinates in the workgroup tile
     const int mrow0 = wm * OROWS;                                         // first tile pixel of this wave
     constexpr int SSTR = WV ? 64 : NTHR;
     const int th = 1 << a.lth, tw = 1 << a.ltw, TB = 1 << a.lTB;
@@ -419,10 +420,10 @@ __global__ __launch_bounds__((LAY == 2 ? 512 : 256), ((NT > 1 || LAY == 2) ? 1 :
         __syncthreads();
         if (tid < NT * 32) {
             float v1 = 0.f, v2 = 0.f;
-            if constexpr (W22) {   // channel tid lives in the two waves of column wn = tid / (32*NTW)
+            if constexpr (W22) {   // channel tid lives in the WM waves of column wn = tid / (32*NTW)
                 const int cw = tid / (32 * NTW), cl = tid - cw * 32 * NTW;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) { v1 += red[(((m + 2 * cw) * NTW) * 32 + cl) * 2]; v2 += red[(((m + 2 * cw) * NTW) * 32 + cl) * 2 + 1]; }
+                for (int m = 0; m < WM; ++m) { v1 += red[(((m + WM * cw) * NTW) * 32 + cl) * 2]; v2 += red[(((m + WM * cw) * NTW) * 32 + cl) * 2 + 1]; }
             } else {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { v1 += red[((w * NT) * 32 + tid) * 2]; v2 += red[((w * NT) * 32 + tid) * 2 + 1]; }

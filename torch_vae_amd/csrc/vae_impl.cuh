@@ -80,6 +80,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     //  wave-independent tiles)
     const bool lay22 = is_down && sizeof(T) == 2 && NT >= 2 && NT >= c->knob_lay22_min_nt;
     const bool lay24 = lay22 && NT == 4 && sizeof(T) == 2 && c->knob_down_waves == 8;    // eight waves: 2 x 4 grid
+    const bool lay42 = lay22 && NT == 2 && sizeof(T) == 2 && c->knob_down_waves == 8 && (c->knob_lay42 != 0);   // eight waves: 4 x 2 grid
     const bool wv = sizeof(T) == 2 && !lay22 && NT <= c->knob_wave_nt_max;
     Tiling t = make_tiling(a.Hs, a.Ws, wv ? 32 : 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
@@ -92,8 +93,8 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     a.n_mt = n_mt; a.rev = ((c->knob_rev >> 2) & 1) ? ((a.epi == EPI_FWD) ? ((c->knob_rev >> 4) & 1) : 1) : 0;   // bit 2: backward launches, bit 4: forward too
     if (c->knob_rev & 32) { a.rev = c->walk_dir; c->walk_dir ^= 1; }   // bit 5: alternate the direction launch by launch
     const size_t opitch = 32 * NT * sizeof(T) + 16;
-    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (lay24 ? 512 * (8 * NT * sizeof(T) + 16) : lay22 ? 256 * (16 * NT * sizeof(T) + 16) : (is_down ? 128 : 256) * opitch) + 4 * NT * 32 * 2 * 4 +
-                       std::max<size_t>((size_t)TB * PHW * 4, lay24 ? (size_t)5 * 512 : (size_t)(is_down ? 10 : 3) * (wv ? 64 : 256)) * 8;   // + the per-item staging table (padded to MAXI*SSTR)
+    const size_t lds = ((3 * a.Cin * 4 + 15) & ~15) + (size_t)(wv ? 4 : 1) * TB * PHW * PATCH_PITCH + (lay24 ? 512 * (8 * NT * sizeof(T) + 16) : lay42 ? 256 * (16 * NT * sizeof(T) + 16) : lay22 ? 256 * (16 * NT * sizeof(T) + 16) : (is_down ? 128 : 256) * opitch) + 4 * NT * 32 * 2 * 4 +
+                       std::max<size_t>((size_t)TB * PHW * 4, (lay24 || lay42) ? (size_t)5 * 512 : (size_t)(is_down ? 10 : 3) * (wv ? 64 : 256)) * 8;   // + the per-item staging table (padded to MAXI*SSTR)
     if (lds > 160 * 1024) return vae_set_error("conv_pipe", "tile does not fit LDS");
     if (c->knob_ablate_b) a.two_src |= 2;
     a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
@@ -111,11 +112,13 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
     if (((a.two_src & 1) != 0) != (a.epi != EPI_FWD)) return vae_set_error("conv_pipe", "forward launches stage one source, backward launches two");
 #define PIPE_CASE(K, N, E, V) { if (set_lds(K<T, N, E, V>, lds)) return -1; hipLaunchKernelGGL((K<T, N, E, V>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
 #define PIPE_CASE22(N, E) { if (set_lds(down2_kernel<T, N, E, false, 1>, lds)) return -1; hipLaunchKernelGGL((down2_kernel<T, N, E, false, 1>), dim3(grid), dim3(256), lds, st, a, n_pairs, ntn); }
+#define PIPE_CASE42(E) { if (set_lds(down2_kernel<T, 2, E, false, 3>, lds)) return -1; hipLaunchKernelGGL((down2_kernel<T, 2, E, false, 3>), dim3(grid), dim3(512), lds, st, a, n_pairs, ntn); }
 #define PIPE_CASE24(E) { if (set_lds(down2_kernel<T, 4, E, false, 2>, lds)) return -1; hipLaunchKernelGGL((down2_kernel<T, 4, E, false, 2>), dim3(grid), dim3(512), lds, st, a, n_pairs, ntn); }
 #define PIPE_WV(K, N, E) { if constexpr (sizeof(T) == 2) { if (wv) PIPE_CASE(K, N, E, true) else PIPE_CASE(K, N, E, false) } else PIPE_CASE(K, N, E, false) }
 #define PIPE_EPI(K, N) { if (a.epi == EPI_FWD) PIPE_WV(K, N, EPI_FWD) else if (a.epi == EPI_BWD) PIPE_WV(K, N, EPI_BWD) else PIPE_WV(K, N, EPI_PLAIN) }
 #define PIPE_EPI22(N) { if (a.epi == EPI_FWD) PIPE_CASE22(N, EPI_FWD) else if (a.epi == EPI_BWD) PIPE_CASE22(N, EPI_BWD) else PIPE_CASE22(N, EPI_PLAIN) }
     if (lay24) { if constexpr (sizeof(T) == 2) { if (a.epi == EPI_FWD) PIPE_CASE24(EPI_FWD) else if (a.epi == EPI_BWD) PIPE_CASE24(EPI_BWD) else PIPE_CASE24(EPI_PLAIN) } }
+    else if (lay42) { if constexpr (sizeof(T) == 2) { if (a.epi == EPI_FWD) PIPE_CASE42(EPI_FWD) else if (a.epi == EPI_BWD) PIPE_CASE42(EPI_BWD) else PIPE_CASE42(EPI_PLAIN) } }
     else if (lay22) { if (NT == 2) PIPE_EPI22(2) else { if constexpr (sizeof(T) == 2) PIPE_EPI22(4) } }
     else if (is_down) { if (NT == 1) PIPE_EPI(down2_kernel, 1) else if (NT == 2) PIPE_EPI(down2_kernel, 2) else PIPE_EPI(down2_kernel, 4) }
     else if (a.epi == EPI_FWD) { if (NT == 1) PIPE_WV(up2_kernel, 1, EPI_FWD) else PIPE_WV(up2_kernel, 2, EPI_FWD) }
@@ -124,6 +127,7 @@ static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
 #undef PIPE_EPI22
 #undef PIPE_EPI
 #undef PIPE_WV
+#undef PIPE_CASE42
 #undef PIPE_CASE24
 #undef PIPE_CASE22
 #undef PIPE_CASE
