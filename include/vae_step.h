@@ -223,6 +223,7 @@ int vae_selftest_tr16(vae_stream_t stream);
  *   knob_nt_max [4], knob_up_per_cu [2] (resident workgroups per CU of the transposed-conv kernels: 2 beats 4 by 2 % of the step, 1 and 3 are worse), knob_down_per_cu [2] (measured flat 1-4), knob_convout_grid [1536], knob_convout_bwd_grid [1024] (persistent workgroups of the output-conv forward / backward kernels; full rounds of what is resident - 768 / 512 - beat 2048 by 1 %; the backward grid equals knob_convout_step_grid so that both partition the tiles alike), knob_pipe_max_cout [256], knob_bwd_per_cu [0],
  *   knob_wgrad_tile [1], knob_wgrad_wide [1], knob_wgrad_wgs [128], knob_wgrad_wide_wgs [128], knob_wgrad_cap_mb [48],
  *   knob_conv1_grid [1024], knob_pack_grid [128], knob_ablate_b [0]   grid / tile sizing
+ *   knob_wgrad_layer_wgs [0]  diagnostic: (layer mask << 16) | workgroups overrides the weight-gradient split of the masked layers
  *   knob_skip_wgrad [0], knob_ablate_f [0]      ablation diagnostics (skip weight-gradient launches by layer mask / phases
  *                           of the encoder.1 fused kernel): results are WRONG when set - timing experiments only */
 int vae_set_option(vae_ctx* ctx, const char* name, int value);

@@ -75,7 +75,7 @@ struct vae_ctx {
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
     hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
     void* nccl_comm = nullptr; int comm_rank = 0, comm_world = 0;   // RCCL communicator owned by the context (vae_comm.hip)
-    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_down_waves, knob_pack_grid, knob_xcd_map, knob_up_nt_max, knob_lay42, knob_conv1_grid, use_fused_bn, knob_rev, knob_lean, walk_dir, bwd_dirty, bwd_half_done;
+    int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_down_waves, knob_pack_grid, knob_xcd_map, knob_up_nt_max, knob_lay42, knob_wgrad_layer_wgs, knob_conv1_grid, use_fused_bn, knob_rev, knob_lean, walk_dir, bwd_dirty, bwd_half_done;
     double* dstats; size_t n_dstats; double* accum;  // accum: [0] bce, [1] kl term, [2] sum dlogit
     double* generic_accum;                           // vae_elbo_generic on this context's device (per context, not process-global)
     WgradKnobs wk;

@@ -168,7 +168,15 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     // knob_wgrad_force_simple diagnostic) take the synchronous kernel, which uses 64-bit element offsets
     const bool fits32 = 4.0 * a.B * a.Hs * a.Ws * std::max(a.CA, a.CB) * sizeof(T) < 4294967296.0 && !c->wk.force_simple;
     const bool pre = c->use_pipelined && sizeof(T) == 2 && fits32;
-    const size_t need = wgrad_slab_floats(c->wk, a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB, pre, big);
+    WgradKnobs wk = c->wk;
+    // per-layer override of the wide-tile split (diagnostic: knob_wgrad_layer_wgs = layer_mask << 16 | workgroups;
+    // bit i of the mask = BN layer i, named by the current tag)
+    if (c->knob_wgrad_layer_wgs && c->tag) {
+        static const char* kTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
+        for (int i = 0; i < 8; ++i)
+            if (!strcmp(c->tag, kTag[i]) && ((c->knob_wgrad_layer_wgs >> (16 + i)) & 1)) wk.wide_wgs = wk.wgs = c->knob_wgrad_layer_wgs & 0xffff;
+    }
+    const size_t need = wgrad_slab_floats(wk, a.B, a.Hs, a.Ws, a.CA, a.CB, &nsplit, &tps, &WA, &WB, pre, big);
     if (need > c->slab_floats) return vae_set_error("wgrad", "slab too small");
     Tiling t = make_tiling(a.Hs, a.Ws, WG_KP);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
