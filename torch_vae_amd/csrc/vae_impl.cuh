@@ -608,7 +608,7 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
                 m.yf = reinterpret_cast<const T*>(c->lay[7].y); m.wt = c->wout_t; m.bias = params + c->poff[39]; m.target = c->x;
                 m.xhat = c->xhat; m.accum = c->accum; m.dz = reinterpret_cast<T*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat;
                 m.B = B; m.H = H; m.W = H; m.n_tiles = B * (H / 8) * (H / 32);
-                m.inv_n = (float)(1.0 / ((double)B * H * H)); m.slope = kSlope; m.gmul = c->gmul;
+                m.inv_n = (float)(1.0 / ((double)B * H * H)); m.slope = kSlope; m.gmul = c->gmul; m.ablate = c->knob_ablate_f;
                 grid = std::min(m.n_tiles, c->knob_convout_step_grid);   // 512 resident (2 per CU by LDS): two full rounds
                 const size_t lds = convout_step_lds();
                 if (set_lds(convout_step_mfma_kernel<T>, lds)) return -1;
