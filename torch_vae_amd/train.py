@@ -148,7 +148,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
     log_wandb = bool(getattr(config, "log_wandb", False))
     if log_wandb:
         import wandb  # lazy, optional (train.py:608-610)
-    loss_epoch = 0
+    loss_epoch_dev = None
     if getattr(config, "print_interval", None) is None:
         config.print_interval = config.log_interval
     world = _dp_world()
@@ -156,6 +156,9 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
              and getattr(criterion, "__self__", None) is model and not getattr(config, "freeze_encoder", False))
     for batch_idx, (stimuli, y_true) in enumerate(dataloader):
         batch_size_this_gpu = stimuli.shape[0]
+        # (blocking copies, as train.py:630-631: measured on MI355X, asynchronous copies of the pinned 16.8 MB batch are SLOWER
+        #  here - 1.80 ms/step on the compute stream, 3.0 ms/step prefetched on a copy stream beside the step - than the
+        #  blocking copy's 1.66 ms/step)
         stimuli = stimuli.to(device)
         y_true = y_true.to(device)
         if fused:
@@ -177,14 +180,24 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
         total_step += 1
         batch_size_all = batch_size_this_gpu * getattr(config, "world_size", world)
         n_samples_seen += batch_size_all
-        loss_batch, loss_recon, loss_kld = out3.tolist()  # one D2H sync for the three .item() of train.py:672-674
-        loss_epoch += loss_batch
-        if epoch <= 1 and batch_idx == 0 and verbose:
+        # The reference reads the three scalars with .item() every step (train.py:672-674), i.e. one host-device round trip
+        # per step.  Here they stay on the device unless this step prints or logs them: the epoch sum is accumulated on the
+        # device in float64, in step order - bit for bit the Python sum of the per-step float32 values.
+        rank0 = getattr(config, "global_rank", 0) == 0
+        printing = batch_idx <= 2 or batch_idx % config.print_interval == 0 or batch_idx >= len(dataloader) - 1
+        logging = log_wandb and rank0 and batch_idx % config.log_interval == 0
+        first_verbose = epoch <= 1 and batch_idx == 0 and verbose
+        if loss_epoch_dev is None:
+            loss_epoch_dev = torch.zeros((), dtype=torch.float64, device=out3.device)
+        loss_epoch_dev += out3[0].double()
+        if (printing and rank0) or logging or first_verbose:
+            loss_batch, loss_recon, loss_kld = out3.tolist()  # one D2H sync for the three .item() of train.py:672-674
+        if first_verbose:
             print("stimuli.shape =", stimuli.shape)
             print("logits.shape  =", reconstruction.shape)
             print("loss =", loss_batch)
-        if batch_idx <= 2 or batch_idx % config.print_interval == 0 or batch_idx >= len(dataloader) - 1:
-            if getattr(config, "global_rank", 0) == 0:
+        if printing:
+            if rank0:
                 print(
                     f"Train Epoch:{epoch:4d}" + (f"/{n_epoch}" if n_epoch is not None else ""),
                     f" Step:{batch_idx + 1:4d}/{len(dataloader)}",
@@ -192,7 +205,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
                     f" LR: {scheduler.get_last_lr()[0]:.5f}",
                     f" KL Weight: {model.kld_weight:.5f}",
                 )
-        if log_wandb and getattr(config, "global_rank", 0) == 0 and batch_idx % config.log_interval == 0:
+        if logging:
             wandb.log({
                 "training/stepwise/epoch": epoch,
                 "training/stepwise/epoch_progress": epoch - 1 + (batch_idx + 1) / len(dataloader),
@@ -202,6 +215,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
                 "training/stepwise/train/loss_kld": loss_kld,
                 "training/stepwise/train/kld_weight": model.kld_weight,
             }, step=total_step)
+    loss_epoch = float(loss_epoch_dev) if loss_epoch_dev is not None else 0.0   # the epoch's one unconditional synchronisation
     results = {"loss": loss_epoch / len(dataloader)}
     return results, total_step, n_samples_seen
 
