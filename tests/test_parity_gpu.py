@@ -1030,8 +1030,19 @@ def test_deferred_output_conv_matches_separate_kernels(dtype):
         _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 15, dz7.data_ptr(), dz7.numel(), torch.cuda.current_stream().cuda_stream), "dbg")
         res.append((out3.clone(), xhat.clone(), dz7, m.flat_grads().clone(), m._bnflat.clone()))
         if fused:     # the deferred forward can be differentiated once, and only through the standard ELBO
-            assert _lib.lib().vae_backward(m._ctx.handle, x.data_ptr(), m._flat.data_ptr(), m._gflat.data_ptr(), 0, 0, 0, 0, 0, 0,
-                                           2.0, 1, torch.cuda.current_stream().cuda_stream) != 0
+            L_, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+            assert L_.vae_backward(m._ctx.handle, x.data_ptr(), m._flat.data_ptr(), m._gflat.data_ptr(), 0, 0, 0, 0, 0, 0, 2.0, 1, st) != 0
+            # a pending train = 2 forward refuses vae_loss (the BCE does not exist yet) and a backward with a loss scale
+            xh, mu_, lv_, z_ = (torch.empty_like(x), *(torch.empty(B, L, device="cuda") for _ in range(3)))
+            assert L_.vae_forward(m._ctx.handle, x.data_ptr(), B, m._flat.data_ptr(), m._bnflat.data_ptr(), m._nbt.data_ptr(),
+                                  eps.data_ptr(), 0, 2, xh.data_ptr(), mu_.data_ptr(), lv_.data_ptr(), z_.data_ptr(), st) == 0
+            o3 = torch.empty(3, device="cuda"); two = torch.full((1,), 2.0, device="cuda")
+            assert L_.vae_loss(m._ctx.handle, 2.0, o3.data_ptr(), st) != 0
+            assert L_.vae_backward(m._ctx.handle, x.data_ptr(), m._flat.data_ptr(), m._gflat.data_ptr(), 0, two.data_ptr(), 0, 0, 0, 0, 2.0, 1, st) != 0
+            assert L_.vae_loss_deferred(m._ctx.handle, 2.0, o3.data_ptr(), st) == 0
+            assert L_.vae_backward(m._ctx.handle, x.data_ptr(), m._flat.data_ptr(), m._gflat.data_ptr(), 0, 0, 0, 0, 0, 0, 2.0, 1, st) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(o3, out3) and torch.equal(xh, xhat)
     (o0, x0, d0, g0, b0), (o1, x1, d1, g1, b1) = res
     assert torch.equal(x0, x1) and torch.equal(o0, o1)
     assert torch.equal(d0, d1)
