@@ -167,6 +167,19 @@ int vae_train_step(vae_ctx* ctx, const float* x, int batch, float* params, float
                    float weight_decay, int step, float* xhat, float* mu, float* log_var, float* z,
                    float* out3, vae_stream_t stream);
 
+/* The fused training step of torch_vae_amd.train.fused_step as ONE host call (train.py:634-659): forward with the output
+ * conv deferred to the backward, ELBO scalars, backward, gradient exchange, AdamW.  exchange: 0 none; 1 one RCCL group over
+ * the optimised ranges between the backward and AdamW; 2 bucketed - the last range (decoder) is all-reduced on the context's
+ * communication stream under the encoder half of the backward, the others after it, and each range's AdamW launch waits only
+ * for its own bucket, so one group's update runs while the other's all-reduce is in flight (the data-parallel layout
+ * train.py:165-166,201,663 prepare).  1 and 2 need vae_comm_init and produce bit-identical results. */
+int vae_train_step_fused(vae_ctx* ctx, const float* x, int batch, float* params, float* grads, float* exp_avg,
+                         float* exp_avg_sq, float* bn_running, int64_t* num_batches_tracked, const float* eps,
+                         uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
+                         const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
+                         float weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu,
+                         float* log_var, float* z, float* out3, vae_stream_t stream);
+
 /* Synthetic pianoroll/line batch with the distribution of data_generators.py:45-77
  * (called as at :97-104), seeded; x [B,1,H,H] f32 in {0,1}.  Device-side generator. */
 int vae_synth_pianoroll(float* x, int batch, int img_size, uint64_t seed, vae_stream_t stream);

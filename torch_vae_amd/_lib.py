@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvae_step_gfx950.so")
+# (VAE_STEP_LIB: a diagnostic build of the same library, e.g. `make STAMPS=1 OUT=... OBJD=...` - see tools/diag/gpu_stamps_deep.py)
+LIB_PATH = os.environ.get("VAE_STEP_LIB") or os.path.join(_HERE, "lib", "libvae_step_gfx950.so")
 
 NUM_PARAMS = 40
 NUM_BN = 8
@@ -77,6 +78,8 @@ def lib():
     _sig(L.vae_adamw_step, i32, [p, p, p, p, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32, i32, p])
     _sig(L.vae_train_step, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32,
                                  i32, p, p, p, p, p, p])
+    _sig(L.vae_train_step_fused, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32,
+                                       i32, i32, p, p, p, p, p, p])
     _sig(L.vae_synth_pianoroll, i32, [p, i32, i32, u64, p])
     _sig(L.vae_profile, i32, [p, i32])
     _sig(L.vae_profile_report, i32, [p, C.c_char_p, i64])
@@ -94,7 +97,7 @@ EXPORTS = [
     "vae_last_error", "vae_abi_version", "vae_param_layout", "vae_bn_layout", "vae_create", "vae_destroy",
     "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_loss_deferred", "vae_elbo_generic",
     "vae_backward", "vae_backward_part", "vae_comm_stream", "vae_comm_unique_id", "vae_comm_init", "vae_comm_world",
-    "vae_comm_destroy", "vae_allreduce_grads", "vae_broadcast_state", "vae_adamw_step", "vae_train_step", "vae_synth_pianoroll", "vae_profile",
+    "vae_comm_destroy", "vae_allreduce_grads", "vae_broadcast_state", "vae_adamw_step", "vae_train_step", "vae_train_step_fused", "vae_synth_pianoroll", "vae_profile",
     "vae_profile_report", "vae_profile_sequence", "vae_profile_timeline", "vae_debug_stamps", "vae_debug_tensor",
     "vae_selftest_tr16", "vae_set_option",
 ]

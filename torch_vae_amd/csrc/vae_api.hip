@@ -82,6 +82,7 @@ extern "C" void vae_destroy(vae_ctx* c) {
         (void)hipStreamSynchronize(c->comm);
         for (int i = 0; i < vae_ctx::NFORK; ++i) (void)hipEventDestroy(c->ev_fork[i]);
         (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_comm);
+        for (int i = 0; i < vae_ctx::NBUCKET; ++i) (void)hipEventDestroy(c->ev_bucket[i]);
     }
     delete c;
 }
@@ -173,7 +174,8 @@ extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
             for (int i = 0; i < vae_ctx::NFORK && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) == hipSuccess;
             if (ok) { c->comm = ds->comm;
                       ok = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) == hipSuccess &&
-                           hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) == hipSuccess; }
+                           hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) == hipSuccess;
+                      for (int i = 0; i < vae_ctx::NBUCKET && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_bucket[i], hipEventDisableTiming) == hipSuccess; }
             c->n_side_ok = ok ? 1 : 0;
         }
     }
@@ -229,6 +231,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }
     if (!strcmp(name, "knob_skip_wgrad")) { c->knob_skip_wgrad = value; return 0; }
     if (!strcmp(name, "use_raw_wgrad")) { c->use_raw_wgrad = value; return 0; }
+    if (!strcmp(name, "use_deep")) { c->use_deep = value; return 0; }
     if (!strcmp(name, "knob_fused_grid")) { c->knob_fused_grid = std::max(1, std::min(value, 512)); return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { c->wk.tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { c->wk.wide = value; return 0; }
@@ -419,6 +422,57 @@ extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, 
     if (vae_loss_deferred(c, kld_weight, out3, stream)) return -1;
     if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
     if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, 1.f, step, stream)) return -1;
+    return 0;
+}
+
+// The fused training step as ONE host call (what torch_vae_amd.train.fused_step enqueues per iteration; train.py:634-659):
+// forward with the output conv deferred (train = 2), ELBO scalars finalised beside the backward, backward, the gradient
+// exchange of a data-parallel job, AdamW.  `exchange`:
+//   0  none (single process);
+//   1  ONE RCCL group over the `ngroups` optimised ranges on the compute stream, between the last backward kernel and AdamW;
+//   2  bucketed: every group's all-reduce runs on the context's communication stream as soon as its gradients are complete
+//      (the LAST group of the list - the decoder - after the first half of the backward, under the encoder half; the others
+//      after the second half), and every group's AdamW launch waits only for its own bucket's event, so the update of one
+//      group runs while the other group's all-reduce is still in flight (train.py:165-166,201,663 prepare this data-parallel
+//      layout; the reference itself never exchanges).  Same arithmetic as 1: results are bit-identical.
+// Modes 1 and 2 need vae_comm_init.  Outputs (xhat, mu, log_var, z, out3) are caller-owned as in vae_forward / vae_loss.
+extern "C" int vae_train_step_fused(vae_ctx* c, const float* x, int B, float* params, float* grads, float* m, float* v, float* bn_running,
+                                    int64_t* nbt, const float* eps, uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
+                                    const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
+                                    float weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu, float* lv,
+                                    float* z, float* out3, vae_stream_t stream) {
+    if (!c) return vae_set_error("vae_train_step_fused", "null ctx");
+    if (exchange < 0 || exchange > 2) return vae_set_error("vae_train_step_fused", "exchange must be 0, 1 or 2");
+    if (exchange && !c->nccl_comm) return vae_set_error("vae_train_step_fused", "gradient exchange without a communicator: call vae_comm_init first");
+    if (exchange && ngroups < 1) return vae_set_error("vae_train_step_fused", "gradient exchange needs the optimised ranges");
+    hipStream_t st = (hipStream_t)stream;
+    if (vae_forward(c, x, B, params, bn_running, nbt, eps, seed, 2, xhat, mu, lv, z, stream)) return -1;
+    if (vae_loss_deferred(c, kld_weight, out3, stream)) return -1;
+    if (exchange != 2) {
+        if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
+        if (exchange == 1 && vae_allreduce_grads(c, grads, ngroups, offsets, sizes, 1, stream)) return -1;
+        if (ngroups > 0 && vae_adamw_step(params, grads, m, v, ngroups, offsets, sizes, lrs, beta1s, beta2, adam_eps, weight_decay, grad_scale, step, stream)) return -1;
+        return 0;
+    }
+    // bucketed exchange
+    if (ngroups > vae_ctx::NBUCKET) return vae_set_error("vae_train_step_fused", "too many groups");
+    if (vae_backward_part(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, 1, stream)) return -1;
+    vae_stream_t cs = nullptr;
+    const int last = ngroups - 1;
+    if (vae_comm_stream(c, stream, &cs)) return -1;                              // ordered after the first half of the backward
+    if (vae_allreduce_grads(c, grads, 1, offsets + last, sizes + last, 1, cs)) return -1;
+    HIP_CHECK_RET(hipEventRecord(c->ev_bucket[last], (hipStream_t)cs));
+    if (vae_backward_part(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, 2, stream)) return -1;   // (joins the communication stream)
+    if (last > 0) {
+        if (vae_comm_stream(c, stream, &cs)) return -1;                          // ordered after the second half
+        if (vae_allreduce_grads(c, grads, last, offsets, sizes, 1, cs)) return -1;
+        for (int i = 0; i < last; ++i) HIP_CHECK_RET(hipEventRecord(c->ev_bucket[i], (hipStream_t)cs));
+    }
+    for (int i = last; i >= 0; --i) {                                            // decoder first: its bucket has long arrived
+        HIP_CHECK_RET(hipStreamWaitEvent(st, c->ev_bucket[i], 0));
+        if (vae_adamw_step(params, grads, m, v, 1, offsets + i, sizes + i, lrs + i, beta1s + i, beta2, adam_eps, weight_decay, grad_scale, step, stream)) return -1;
+    }
+    c->comm_busy = 0;                                                            // every piece of work on the communication stream has been waited for
     return 0;
 }
 

@@ -73,6 +73,7 @@ struct vae_ctx {
     // side streams for work only the optimiser consumes (weight gradients, their split-K reductions) and for weight packing
     static constexpr int NSIDE = 3, NFORK = 16;
     hipStream_t side[NSIDE]; float* side_slab[NSIDE]; hipEvent_t ev_fork[NFORK], ev_join[NSIDE], ev_pack; int side_rr, fork_rr, n_side_ok;
+    static constexpr int NBUCKET = 2; hipEvent_t ev_bucket[NBUCKET];   // bucketed gradient exchange (vae_train_step_fused): bucket i reduced on the communication stream
     hipStream_t comm; hipEvent_t ev_comm; int comm_busy;   // stream lent to the caller for the mid-backward gradient all-reduce (vae_comm_stream)
     void* nccl_comm = nullptr; int comm_rank = 0, comm_world = 0;   // RCCL communicator owned by the context (vae_comm.hip)
     int use_side_stream, knob_bwd_per_cu, knob_wave_nt_max, knob_lay22_min_nt, knob_down_waves, knob_pack_grid, knob_xcd_map, knob_up_nt_max, knob_lay42, knob_wgrad_layer_wgs, knob_conv1_grid, use_fused_bn, knob_rev, knob_lean, walk_dir, bwd_dirty, bwd_half_done;
@@ -89,6 +90,8 @@ struct vae_ctx {
     // side effect by the kernel that stages them first) as plain copies.  Bit-identical; measured 1 % SLOWER in the step on MI355X
     // (the extra stores cost the chain more than the weight-gradient kernels gain: their time is not in the staging arithmetic).
     int use_raw_wgrad = 0;
+    // use_deep: workgroup-specialised kernels of the deep layers (conv_deep.cuh).  bit 0: stride-2 conv products (dn3), bit 1: transposed products (up3)
+    int use_deep = 3;
     int knob_skip_wgrad = 0;  // diagnostics: bit i skips the separate weight-gradient launch of BN layer i (results wrong, timing only)
     int knob_ablate_f = 0;   // diagnostics: phase ablation of conv_bwd_fused_kernel (timing only)
     // use_fused_convout: a forward with train = 2 (the fused training step) leaves the output conv, sigmoid and BCE to the

@@ -6,6 +6,7 @@
 #include "conv_pipe.cuh"
 #include "edge_kernels.cuh"
 #include "conv_fused.cuh"
+#include "conv_deep.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -21,8 +22,61 @@ template <typename T> static int launch_conv_pipe(vae_ctx* c, ConvArgs<T> a, boo
 // the pipelined kernels index their tensors with 32-bit byte offsets (and signed 32-bit element offsets)
 template <typename T> static bool fits_i32(const ConvArgs<T>& a) { return 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) * sizeof(T) < 4294967296.0 && 4.0 * a.B * a.Hs * a.Ws * std::max(a.Cin, a.Cout) < 2147483648.0; }
 
+
+// Workgroup-specialised kernels of the deep layers (conv_deep.cuh): 16-bit storage, 128-pixel tiles of 8x16 pixels or two 8x8
+// images, 128 (down) / 64 (up) output channels per workgroup.  Returns 1 when the launch is outside their domain (the caller
+// then takes the pipelined kernels), 0 on success, -1 on error.
+template <typename T>
+static int launch_conv_deep(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return 1;
+    else {
+        if (!(c->use_deep & (is_down ? 1 : 2)) || !fits_i32(a) || a.stage_out || c->knob_ablate_b) return 1;
+        const int NCO = is_down ? 128 : 64;
+        if (a.Cout % NCO || a.Cin % 32 || a.Cin > 256) return 1;
+        if (((a.two_src & 1) != 0) != (a.epi != EPI_FWD)) return 1;
+        if (!is_down && a.epi == EPI_PLAIN) return 1;
+        Tiling t = make_tiling(a.Hs, a.Ws, 128);
+        const int TB = 1 << t.lTB, th = 1 << t.lth, tw = 1 << t.ltw;
+        if (!((tw == 16 && th == 8 && TB == 1) || (tw == 8 && th == 8 && TB == 2))) return 1;
+        if ((a.two_src & 1) && a.slope != 1.f) return vae_set_error("conv_deep", "gradient operands are loaded without LeakyReLU (slope must be 1)");
+        a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+        a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
+        const int n_mt = ((a.B + TB - 1) / TB) * t.tiles_x * t.tiles_y, ntn = a.Cout / NCO, n_pairs = n_mt * ntn;
+        a.n_mt = n_mt; a.rev = ((c->knob_rev >> 2) & 1) ? ((a.epi == EPI_FWD) ? ((c->knob_rev >> 4) & 1) : 1) : 0;
+        DeepConvArgs<T> d; memset(&d, 0, sizeof(d));
+        // LDS patch rows: a 32-pixel fragment read must touch 16 distinct 16-byte bank groups (conv_deep.cuh)
+        const int PH = is_down ? 2 * th + 1 : th + 1;
+        if (is_down) { d.rowp = tw == 16 ? 40 : 20; d.halfw = tw + 1; }
+        else { d.rowp = tw == 16 ? 32 : 24; d.halfw = 0; }
+        d.imgp = PH * d.rowp; d.npl = TB * d.imgp;
+        d.m_rowp = fastdiv_magic(d.rowp); d.m_imgp = fastdiv_magic(d.imgp);
+        if (d.npl > 64 * (is_down ? 12 : 7)) return vae_set_error("conv_deep", "patch larger than the producers' slot table");
+        int grid = std::min(n_pairs, 256);
+        grid = std::max(ntn, grid / ntn * ntn);   // a workgroup keeps one N tile (register-resident statistics)
+        a.xcd = (c->knob_xcd_map && grid % 8 == 0 && (grid / 8) % ntn == 0) ? grid / 8 : 0;
+        const size_t lds = (size_t)((3 * a.Cin * 4 + 15) & ~15) + 2 * (size_t)d.npl * 80 +
+                           (is_down ? 2 * (size_t)(3 * 4 * 128 * 16) + 4 * 2 * 32 * 2 * 4 : 2 * (size_t)(9 * 4 * 64 * 16) + 4 * 32 * 2 * 4);
+        if (is_down && (size_t)d.npl * 80 < 4 * 64 * 144) return vae_set_error("conv_deep", "patch half smaller than the epilogue tiles");
+        if (lds > 160 * 1024) return vae_set_error("conv_deep", "tile does not fit LDS");
+        a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
+        d.c = a;
+        const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
+        const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
+        ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
+                     sizeof(T) * (px_in * a.Cin * ((a.two_src & 1) ? 2 : 1) + px_out * a.Cout * (a.epi == EPI_BWD ? 2 : 1) + 9.0 * a.Cin * a.Cout),
+                     2.0 * 9 * a.Cin * a.Cout * px_lo, st);
+#define DEEP_CASE(K, E) { if (set_lds(K<T, E>, lds)) return -1; hipLaunchKernelGGL((K<T, E>), dim3(grid), dim3(512), lds, st, d, n_pairs, ntn); }
+        if (is_down) { if (a.epi == EPI_FWD) DEEP_CASE(dn3_kernel, EPI_FWD) else if (a.epi == EPI_BWD) DEEP_CASE(dn3_kernel, EPI_BWD) else DEEP_CASE(dn3_kernel, EPI_PLAIN) }
+        else { if (a.epi == EPI_FWD) DEEP_CASE(up3_kernel, EPI_FWD) else DEEP_CASE(up3_kernel, EPI_BWD) }
+#undef DEEP_CASE
+        LAUNCH_CHECK("conv_deep_kernel");
+        return 0;
+    }
+}
+
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if (c->use_pipelined) { const int rc = launch_conv_deep<T>(c, a, true, st); if (rc <= 0) return rc; }
     if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, true, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
@@ -45,6 +99,7 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 
 template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if (c->use_pipelined) { const int rc = launch_conv_deep<T>(c, a, false, st); if (rc <= 0) return rc; }
     if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, false, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
     a.lth = t.lth; a.ltw = t.ltw; a.lTB = t.lTB; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
