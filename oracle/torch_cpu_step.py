@@ -67,15 +67,16 @@ class TorchCpuStep:
         return float(loss.detach()), float(recon.detach()), float(-kld.detach())
 
 
-def time_cpu_baseline(img_size, latent_dim, batch, generalised=True, budget_s=20.0, max_steps=50, threads=None, seed=0):
+def time_cpu_baseline(img_size, latent_dim, batch, generalised=True, budget_s=20.0, max_steps=50, threads=None, seed=0, warmup=1):
     """samples/s of the CPU port on a bounded sample of the bench workload."""
     if threads:
         torch.set_num_threads(threads)
     params = vo.init_params(latent_dim, img_size, seed, generalised)
-    st = TorchCpuStep(params, batch=batch, total_steps=max_steps + 2)
+    st = TorchCpuStep(params, batch=batch, total_steps=max_steps + max(1, warmup) + 1)
     x = torch.from_numpy(vo.synth_pianoroll(batch, img_size, seed))
     eps = torch.from_numpy(vo.counter_normal(batch * latent_dim, seed, 5).reshape(batch, latent_dim)).float()
-    st.step(x, eps)  # warm-up
+    for _ in range(max(1, warmup)):
+        st.step(x, eps)  # warm-up
     t0 = time.perf_counter()
     n = 0
     while n < max_steps and (time.perf_counter() - t0) < budget_s:

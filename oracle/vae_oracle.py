@@ -288,6 +288,36 @@ def sigmoid(v):
 
 
 # --------------------------------------------------------------------------
+# storage emulation (16-bit kernel modes)
+# --------------------------------------------------------------------------
+def round_storage(a: np.ndarray, storage: str | None, scale: float = 1.0) -> np.ndarray:
+    """Round to the grid of the HIP path's 16-bit storage type ("bf16" / "f16"; None: identity), round-to-nearest-even, keeping
+    the array's dtype.  `scale` (a power of two): the f16 mode stores its gradients multiplied by it (torch_vae_amd/csrc/vae_ctx.h:
+    gmul), so they are rounded on the scaled values."""
+    if storage is None:
+        return a
+    v = a * a.dtype.type(scale) if scale != 1.0 else a
+    if storage == "f16":
+        with np.errstate(over="ignore"):
+            r = v.astype(np.float16).astype(a.dtype)
+    elif storage == "bf16":
+        f = np.ascontiguousarray(v, dtype=np.float32)
+        u = f.view(np.uint32)
+        with np.errstate(over="ignore"):
+            u = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+        r = u.view(np.float32).astype(a.dtype)
+    else:
+        raise ValueError(storage)
+    return r / a.dtype.type(scale) if scale != 1.0 else r
+
+
+def f16_grad_scale(batch: int, img_size: int) -> float:
+    """Gradient scale of the f16 kernel mode (vae_impl.cuh forward_impl: 2^(ilog2 B + 2 ilog2 H - 4), ilog2 = ceil(log2))."""
+    il = lambda v: int(math.ceil(math.log2(v))) if v > 1 else 0   # noqa: E731
+    return float(2 ** max(0, il(batch) + 2 * il(img_size) - 4))
+
+
+# --------------------------------------------------------------------------
 # model forward / loss / backward
 # --------------------------------------------------------------------------
 _ENC = [f"encoder.{i}" for i in range(4)]
@@ -295,16 +325,22 @@ _DEC = [f"decoder.{i}" for i in range(3)]
 
 
 def forward(p: dict, x: np.ndarray, eps: np.ndarray, bn_state: dict | None = None,
-            train: bool = True, update_running: bool = True) -> dict:
+            train: bool = True, update_running: bool = True, storage: str | None = None) -> dict:
     """models.py:185-188 (encode :107-145, reparameterize :177-183, decode :147-175).
 
     eps is the N(0,1) draw that torch.randn_like would supply (H5: passed
     explicitly for parity).  Returns a dict with every intermediate needed by
     backward plus the ModelOutput fields.
+
+    storage ("bf16" / "f16"): emulate the rounding points of the HIP path's 16-bit kernel modes: every raw
+    conv output y_l is STORED rounded (BatchNorm statistics are those of the stored tensor), the staged operand LeakyReLU(BN(y_l))
+    is rounded when it enters a matrix product, the weights of the MFMA layers are rounded (packed images), decoder_input's
+    output is stored rounded; accumulation, statistics, the latent block and the loss stay in the oracle's precision.
     """
     dt = x.dtype
-    c = {"x": x, "eps": eps}
+    c = {"x": x, "eps": eps, "storage": storage}
     a = x
+    rs = lambda v: round_storage(v, storage)   # noqa: E731
 
     def bn(name, y):
         g, b = p[name + ".weight"], p[name + ".bias"]
@@ -320,36 +356,38 @@ def forward(p: dict, x: np.ndarray, eps: np.ndarray, bn_state: dict | None = Non
         z = bn_eval_fwd(y, g, b, bn_state[name + ".running_mean"].astype(dt), bn_state[name + ".running_var"].astype(dt))
         return z, None
 
-    for name in _ENC:
-        c[name + ".in"] = a
-        y = conv_fwd(a, p[name + ".0.weight"], p[name + ".0.bias"], 2)
+    for i, name in enumerate(_ENC):
+        c[name + ".in"] = a                      # (already rounded where the HIP path stages it rounded)
+        w = p[name + ".0.weight"] if i == 0 else rs(p[name + ".0.weight"])   # encoder.0 reads the f32 weights (conv1_fwd)
+        y = rs(conv_fwd(a, w, p[name + ".0.bias"], 2))
         z, cache = bn(name + ".1", y)
         c[name + ".y"], c[name + ".z"], c[name + ".bn"] = y, z, cache
-        a = lrelu(z)
+        c[name + ".act"] = lrelu(z)              # unrounded (the fc weight gradient / pre_latents use it in f32)
+        a = rs(c[name + ".act"])
     B = x.shape[0]
     c["enc_shape"] = a.shape
-    pre = a.reshape(B, -1)
-    mu = pre @ p["fc_mu.weight"].T + p["fc_mu.bias"]
-    lv = pre @ p["fc_var.weight"].T + p["fc_var.bias"]
+    pre = a.reshape(B, -1)                       # staged (rounded) operand of the fc products
+    mu = pre @ rs(p["fc_mu.weight"]).T + p["fc_mu.bias"]
+    lv = pre @ rs(p["fc_var.weight"]).T + p["fc_var.bias"]
     std = np.exp(dt.type(0.5) * lv)
     zlat = eps * std + mu
-    d0 = zlat @ p["decoder_input.weight"].T + p["decoder_input.bias"]
+    d0 = rs(zlat @ p["decoder_input.weight"].T + p["decoder_input.bias"])
     s = int(round(math.sqrt(d0.shape[1] // 256)))
     a = d0.reshape(-1, 256, s, s)  # models.py:166 (generalised: s = H/16)
-    c.update(pre=pre, mu=mu, lv=lv, std=std, zlat=zlat)
+    c.update(pre=c[_ENC[-1] + ".act"].reshape(B, -1), mu=mu, lv=lv, std=std, zlat=zlat)
     for name in _DEC:
         c[name + ".in"] = a
-        y = convT_fwd(a, p[name + ".0.weight"], p[name + ".0.bias"])
+        y = rs(convT_fwd(a, rs(p[name + ".0.weight"]), p[name + ".0.bias"]))
         z, cache = bn(name + ".1", y)
         c[name + ".y"], c[name + ".z"], c[name + ".bn"] = y, z, cache
-        a = lrelu(z)
+        a = rs(lrelu(z))
     c["final_layer.in"] = a
-    y = convT_fwd(a, p["final_layer.0.weight"], p["final_layer.0.bias"])
+    y = rs(convT_fwd(a, rs(p["final_layer.0.weight"]), p["final_layer.0.bias"]))
     z, cache = bn("final_layer.1", y)
     c["final_layer.y"], c["final_layer.z"], c["final_layer.bn"] = y, z, cache
-    a = lrelu(z)
+    a = rs(lrelu(z))
     c["final_conv.in"] = a
-    logits = conv_fwd(a, p["final_layer.3.weight"], p["final_layer.3.bias"], 1)
+    logits = conv_fwd(a, rs(p["final_layer.3.weight"]), p["final_layer.3.bias"], 1)
     c["logits"] = logits
     c["output"] = sigmoid(logits)
     return c
@@ -375,25 +413,35 @@ def backward(p: dict, c: dict, kld_weight: float = 1.0) -> dict:
     g = {}
     xh, t = c["output"], c["x"]
     N = xh.size
+    # storage emulation (see forward): stored gradients dz_l and the staged BatchNorm-backward gradients are rounded (on values
+    # multiplied by the f16 mode's gradient scale), gradient products use the rounded weights; sums stay in the oracle's precision
+    storage = c.get("storage")
+    gs = f16_grad_scale(xh.shape[0], xh.shape[2]) if storage == "f16" else 1.0
+    rs = lambda v: round_storage(v, storage)            # noqa: E731
+    rg = lambda v: round_storage(v, storage, gs)        # noqa: E731
     # F.binary_cross_entropy backward (ATen): (x-t)/max(x(1-x),1e-12) * grad
     d_xh = (xh - t) / np.maximum(xh * (1 - xh), dt.type(1e-12)) / dt.type(N)
     dlogit = d_xh * xh * (1 - xh)
     a = c["final_conv.in"]
-    dw, db = conv_wgrad(a, dlogit, 1)
-    g["final_layer.3.weight"], g["final_layer.3.bias"] = dw, db
-    da = conv_dgrad(dlogit, p["final_layer.3.weight"], 1, a.shape[2:])
+    dl_op = rg(dlogit)                                  # the MFMA operand of the output conv's gradient products
+    dw, _ = conv_wgrad(a, dl_op, 1)
+    g["final_layer.3.weight"], g["final_layer.3.bias"] = dw, dlogit.sum(axis=(0, 2, 3))
+    da = conv_dgrad(dl_op, rs(p["final_layer.3.weight"]), 1, a.shape[2:])
 
     def block_bwd(name, bn_name, da, transposed):
-        dz = lrelu_bwd(c[name + ".z"], da)
+        dz = rg(lrelu_bwd(c[name + ".z"], da))
         g[name + ".dz"] = dz
         dy, dgam, dbet = bn_train_bwd(dz, p[bn_name + ".weight"], c[name + ".bn"])
         g[bn_name + ".weight"], g[bn_name + ".bias"] = dgam, dbet
+        first = name == _ENC[0]                         # encoder.0: f32 weights and an unrounded gradient operand (conv1_wgrad)
+        dyr = dy if first else rg(dy)
         xin = c[name + ".in"]
+        w = p[name + ".0.weight"] if first else rs(p[name + ".0.weight"])
         if transposed:
-            dx, dw, db = convT_bwd(xin, p[name + ".0.weight"], dy)
+            dx, dw, db = convT_bwd(xin, w, dyr)
         else:
-            dw, db = conv_wgrad(xin, dy, 2)
-            dx = conv_dgrad(dy, p[name + ".0.weight"], 2, xin.shape[2:])
+            dw, db = conv_wgrad(xin, dyr, 2)
+            dx = conv_dgrad(dyr, w, 2, xin.shape[2:])
         g[name + ".0.weight"], g[name + ".0.bias"] = dw, db
         return dx
 
@@ -401,11 +449,11 @@ def backward(p: dict, c: dict, kld_weight: float = 1.0) -> dict:
     for name in reversed(_DEC):
         da = block_bwd(name, name + ".1", da, True)
     B = da.shape[0]
-    dd0 = da.reshape(B, -1)
+    dd0 = rg(da).reshape(B, -1)                         # stored by decoder.0's input-gradient kernel
     g["__dd0"] = dd0
     g["decoder_input.weight"] = dd0.T @ c["zlat"]
     g["decoder_input.bias"] = dd0.sum(axis=0)
-    dzlat = dd0 @ p["decoder_input.weight"]
+    dzlat = dd0 @ rs(p["decoder_input.weight"])
     mu, lv = c["mu"], c["lv"]
     kw = dt.type(kld_weight)
     dmu = dzlat + kw * mu / B
@@ -414,7 +462,7 @@ def backward(p: dict, c: dict, kld_weight: float = 1.0) -> dict:
     g["fc_mu.bias"] = dmu.sum(axis=0)
     g["fc_var.weight"] = dlv.T @ c["pre"]
     g["fc_var.bias"] = dlv.sum(axis=0)
-    dpre = dmu @ p["fc_mu.weight"] + dlv @ p["fc_var.weight"]
+    dpre = dmu @ rs(p["fc_mu.weight"]) + dlv @ rs(p["fc_var.weight"])
     da = dpre.reshape(c["enc_shape"])
     for name in reversed(_ENC):
         da = block_bwd(name, name + ".1", da, False)

@@ -35,6 +35,9 @@ GRAD_TOL = {"f32": 5e-3, "bf16": 0.28, "f16": 0.14}
 GRAD_TOL_FULL = {"bf16": 2e-2, "f16": 8e-3}              # flat gradient vs the f32 mode at full size
 GRAD_TOL_FIXTURE = {"bf16": 8e-2, "f16": 4e-2}           # per-tensor gradient NORM vs the reference fixture
 FWD_TOL = {"f32": 1e-4, "bf16": 2e-2, "f16": 3e-3}        # xhat rel-L2
+# against the oracle run with the kernels' storage rounding emulated (same rounding points): per-tensor gradient rel-L2 / ELBO
+EMU_GRAD_TOL = {"bf16": 5e-2, "f16": 2e-2}
+EMU_ELBO_TOL = {"bf16": 2e-3, "f16": 5e-4}
 
 
 def report(**kw):
@@ -121,6 +124,22 @@ def test_every_tensor_against_oracle(cfg, dtype):
     assert rel_l2(model._last["mu"].cpu().numpy(), c["mu"]) < 1.5 * FWD_TOL[dtype]
     for n, gap in gaps.items():
         assert gap < GRAD_TOL[dtype], (n, gap)
+    if dtype != "f32":
+        # The same step against the oracle with the kernels' STORAGE emulated (y_l, dz_l, the staged operands and the packed weights
+        # rounded where the kernels round them: oracle/vae_oracle.py forward/backward(storage=...)).  This separates the two
+        # error sources the wide gate above lumps together: what remains here is the kernels' own arithmetic (accumulation order,
+        # f32 instead of f64 statistics), so the gate is tight.
+        ce = vo.forward(p, x.astype(np.float64), eps, None, train=True, storage=dtype)
+        le = vo.loss(ce)
+        ge = vo.backward(p, ce)
+        wante = np.array([float(le["loss"]), float(le["reconstruction_loss"]), float(le["kld_loss"])])
+        gaps_e = {n: rel_l2(v, ge[n].reshape(-1)) for n, v in got.items() if n not in PRE_BN_BIAS}
+        worst_e = max(gaps_e, key=gaps_e.get)
+        report(test="every_tensor_vs_emulated_storage", cfg=list(cfg), dtype=dtype, elbo_rel=float(np.abs(got3 / wante - 1).max()),
+               xhat_rel_l2=rel_l2(xhat.cpu().numpy(), ce["output"]), grad_rel_l2_max=gaps_e[worst_e], worst=worst_e)
+        np.testing.assert_allclose(got3, wante, rtol=EMU_ELBO_TOL[dtype])
+        for n, gap in gaps_e.items():
+            assert gap < EMU_GRAD_TOL[dtype], (n, gap, "vs the storage-emulating oracle")
 
 
 def test_tr16_and_scalar_wgrad_agree():
@@ -323,11 +342,25 @@ def test_train_one_epoch_matches_reference_loop():
     epss = [torch.from_numpy(case_inputs(name, s)[1]).float().cuda() for s in range(steps)]
     loader = [(torch.from_numpy(case_inputs(name, s)[0]), torch.zeros(B, dtype=torch.long)) for s in range(steps)]
     it = iter(epss)
-    orig = model.fused_forward_backward
-    model.fused_forward_backward = lambda x, **k: orig(x, eps=next(it))
+    # (the loop takes its step through the one-call path, VanillaVAE.fused_train_step: the reference's noise is injected there)
+    orig = model.fused_train_step
+    model.fused_train_step = lambda o, x, **k: orig(o, x, **{**k, "eps": next(it)})
     res, total_step, n_seen = train_one_epoch(cfg, model, opt, sched, model.loss, loader, device="cuda", epoch=2)
     assert total_step == steps and n_seen == steps * B
     np.testing.assert_allclose(res["loss"], gold["losses"][:, 0].mean(), rtol=2e-4)
+    # the same loop through the five-call path (VAE_ONE_CALL_STEP=0): identical trajectory
+    model2 = make_model(H, L, gen, "f32", vo.init_params(L, H, seed, gen), kld_weight=kw)
+    opt2, sched2 = build_optimizer(cfg, model2, steps_per_epoch=total)
+    it2 = iter(epss)
+    orig2 = model2.fused_forward_backward
+    model2.fused_forward_backward = lambda x, **k: orig2(x, **{**k, "eps": next(it2)})
+    os.environ["VAE_ONE_CALL_STEP"] = "0"
+    try:
+        res2, _, _ = train_one_epoch(cfg, model2, opt2, sched2, model2.loss, loader, device="cuda", epoch=2)
+    finally:
+        del os.environ["VAE_ONE_CALL_STEP"]
+    assert res2["loss"] == res["loss"]
+    assert torch.equal(model2.flat_parameters(), model.flat_parameters())
 
 
 def test_pipelined_and_simple_conv_kernels_agree():
@@ -724,6 +757,62 @@ def test_full_size_baseline_configs(cfg):
         assert ggap < GRAD_TOL_FULL[dtype]
 
 
+# BASELINE.json single-GPU configurations at FULL size against the torch-CPU oracle (oracle/torch_cpu_step.py, pinned to the
+# reference by tests/test_oracle.py): configs[1] 128x128 L16 B256, configs[2] 256x256 L64 B512, configs[4] 128x128 L128 B512 beta 16.
+FULL_ORACLE = [(128, 16, 256, 1.0), (128, 128, 512, 16.0), (256, 64, 512, 1.0)]
+
+
+@pytest.mark.parametrize("cfg", FULL_ORACLE, ids=[f"{h}x{h}-L{l}-B{b}-k{int(k)}" for h, l, b, k in FULL_ORACLE])
+def test_full_size_against_cpu_oracle(cfg):
+    """The f32 kernel mode at the full BASELINE sizes against the oracle ON THE SAME weights / batch / eps: ELBO scalars and
+    mu / log_var within 1e-4 (north_star), the whole flat gradient within 5e-3 rel-L2 (LeakyReLU kink ties) and
+    every parameter tensor's gradient within 2e-2.  Then the 16-bit modes against that same oracle result, their gaps
+    reported and bounded (the indexing of every layer at full batch is covered: a deterministic, linear large-batch bug
+    in a middle layer would pass the size-independent property tests above, not this one)."""
+    from oracle.torch_cpu_step import TorchCpuStep
+    import torch.nn.functional as F
+    H, L, B, kw = cfg
+    p = perturbed_params(L, H, 5, True)
+    x_np = vo.synth_pianoroll(B, H, 77)
+    eps_np = vo.counter_normal(B * L, 77, 5).reshape(B, L).astype(np.float32)
+    # oracle: forward, ELBO, backward (train.py:634-650) on the host
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    st = TorchCpuStep(p, kld_weight=kw, batch=B, total_steps=4)
+    xc = torch.from_numpy(x_np)
+    xhat_c, mu_c, lv_c, _ = st.forward(xc, torch.from_numpy(eps_np))
+    recon = F.binary_cross_entropy(xhat_c, xc)
+    kld = -0.5 * torch.mean(torch.sum(1 + lv_c - mu_c ** 2 - torch.exp(lv_c), dim=-1))
+    (recon + kw * kld).backward()
+    want3 = np.array([float(recon + kw * kld), float(recon), float(-kld)])
+    gref = {k: v.grad.detach().numpy().ravel().astype(np.float64) for k, v in st.p.items()}
+    mu_c, lv_c = mu_c.detach().numpy(), lv_c.detach().numpy()
+    del xhat_c, recon, kld, st
+    names = [n for n in gref if n not in PRE_BN_BIAS]   # (conv biases in front of a train-mode BatchNorm: analytically zero, DESIGN.md)
+    ref_flat = np.concatenate([gref[n] for n in names])
+    x = torch.from_numpy(x_np).cuda(); eps = torch.from_numpy(eps_np).cuda()
+    for dtype in ("f32", "bf16", "f16"):
+        if dtype == "f32" and H == 256:
+            continue   # (f32 storage at 256x256 / 512 takes the slow 64-bit-offset kernels: the f32 mode is covered at the 128x128 sizes)
+        model = make_model(H, L, True, dtype, p, kld_weight=kw)
+        out3, _ = model.fused_forward_backward(x, eps=eps)
+        got3 = out3.cpu().numpy().astype(np.float64)
+        g = flat_grad_dict(model)
+        got_flat = np.concatenate([g[n].astype(np.float64) for n in names])
+        elbo_gap = float(np.max(np.abs(got3 / want3 - 1)))
+        mu_gap = rel_l2(model._last["mu"].cpu().numpy(), mu_c); lv_gap = rel_l2(model._last["lv"].cpu().numpy(), lv_c)
+        flat_gap = rel_l2(got_flat, ref_flat)
+        worst = max(((rel_l2(g[n], gref[n]), n) for n in names), key=lambda t: t[0])
+        report(test="full_size_vs_cpu_oracle", cfg=list(cfg), dtype=dtype, elbo_rel=elbo_gap, mu_rel_l2=mu_gap, log_var_rel_l2=lv_gap,
+               flat_grad_rel_l2=flat_gap, worst_tensor=worst[1], worst_tensor_rel_l2=worst[0])
+        if dtype == "f32":
+            assert elbo_gap < 1e-4 and mu_gap < 1e-4 and lv_gap < 1e-4, (cfg, elbo_gap, mu_gap, lv_gap)
+            assert flat_gap < 5e-3 and worst[0] < 2e-2, (cfg, flat_gap, worst)
+        else:
+            assert elbo_gap < ELBO_TOL[dtype] and mu_gap < FWD_TOL[dtype] and lv_gap < FWD_TOL[dtype], (cfg, dtype, elbo_gap, mu_gap, lv_gap)
+            assert flat_gap < GRAD_TOL_FULL[dtype] and worst[0] < GRAD_TOL_FIXTURE[dtype], (cfg, dtype, flat_gap, worst)
+        del model
+
+
 def test_bce_edges_and_saturating_logits_on_hip():
     """ATen's BCE conventions (log clamp -100, gradient clamp 1e-12; reference models.py:208) on the HIP kernels:
     the reference-generated edge fixture through vae_elbo_generic, and saturating logits through the fused
@@ -897,8 +986,9 @@ def test_data_parallel_product_path_two_ranks():
 
 def test_library_allreduce_single_rank_rccl():
     """vae_comm_init / vae_allreduce_grads / vae_broadcast_state on a real RCCL communicator (one rank: the only size a
-    one-GPU box can form): the overlapped and the in-line exchange both leave the step unchanged bit for bit, and
-    train.fused_step routes through the library when asked to."""
+    one-GPU box can form): the bucketed exchange (vae_train_step_fused exchange = 2: decoder bucket on the communication stream
+    under the encoder backward, each group's AdamW behind its own bucket's event) and the in-line exchange (exchange = 1) both
+    leave two consecutive steps unchanged bit for bit, and train.fused_step routes through the library when asked to."""
     import ctypes as C
     import torch.distributed as dist
     from torch_vae_amd import _lib
@@ -915,6 +1005,8 @@ def test_library_allreduce_single_rank_rccl():
         if mode is not None:
             assert enable_library_allreduce(m)
         out3, _ = fused_step(m, opt, x, eps=eps, overlap=mode)
+        out3 = out3.clone()
+        fused_step(m, opt, x, eps=eps, overlap=mode)          # a second step: the update of the first one went through the bucketed / in-line AdamW launches
         if mode is not None:
             assert m.library_comm_world() == 1
             st = torch.cuda.current_stream().cuda_stream

@@ -14,14 +14,14 @@ model.fused_forward_backward(x)
 Lb = _lib.lib()
 for k, v in (json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}).items():
     assert Lb.vae_set_option(model._ctx.handle, k.encode(), v) == 0
-names = ["prologue", "fill", "work", "step_wait", "epilogue", "total", "tile_wait", "-"]
-for tag, epi in [("encoder.3", 0), ("encoder.2", 0), ("decoder.0", 2), ("decoder.1", 1), ("decoder.0", 16), ("decoder.1", 16), ("encoder.3", 17), ("encoder.2", 17)]:
-    buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
+names = ["prologue(after setup)", "fill", "work", "step_barrier", "epilogue", "total", "tile_wait", "setup", "dma_issue", "dma_wait"]
+for tag, epi in [("encoder.3", 0), ("encoder.2", 0), ("decoder.0", 2), ("decoder.1", 1)]:
+    buf = torch.zeros(256 * 8 * 16, dtype=torch.int64, device="cuda")
     Lb.vae_debug_stamps(model._ctx.handle, tag.encode(), epi, buf.data_ptr())
     model.fused_forward_backward(x); torch.cuda.synchronize()
     Lb.vae_debug_stamps(model._ctx.handle, b"", 0, None)
-    t = buf.view(-1, 8, 8).double()          # [workgroup][wave][slot]
+    t = buf.view(-1, 8, 16).double()          # [workgroup][wave][slot]
     t = t[t[:, :, 5].sum(1) > 0]
     for role, sl in (("consumers", slice(0, 4)), ("producers", slice(4, 8))):
         m = t[:, sl, :].mean((0, 1))
-        print(f"{tag} epi={epi} {role}: workgroups {t.shape[0]} ->", {n: f"{m[k].item():.0f}" for k, n in enumerate(names[:7])})
+        print(f"{tag} epi={epi} {role}: workgroups {t.shape[0]} ->", {n: f"{m[k].item():.0f}" for k, n in enumerate(names)})

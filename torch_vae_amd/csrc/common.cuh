@@ -178,7 +178,7 @@ struct BnFuse {
     float* block;                   // LC_* rows, stride C
     float* running_mean; float* running_var; long long* nbt;
     float* dgamma; float* dbeta; float* dconv_bias;
-    double count; float eps, momentum;
+    double count, inv_count; float eps, momentum;   // inv_count = 1 / count (host)
     float ginv;                     // backward: dgamma / dbeta are written times ginv (f16 gradient scaling, vae_ctx::ginv)
     int C, mode, update_running;    // mode 0: coefficients are read from the block; 1: forward; 2: backward
 };
@@ -188,10 +188,15 @@ __device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool wr
                                                  float* invstd_out = nullptr, float* xm_out = nullptr) {
     const int C = f.C;
     if (f.mode == BNF_FWD) {
-        const double mean = stat_sum(f.stat, C, c) / f.count;
-        double var = stat_sum(f.stat, C, C + c) / f.count - mean * mean;
+        // (every workgroup of every consumer kernel runs this in its prologue: no f64 division or square root on that path - the
+        //  reciprocal count comes from the host, 1/sqrt from v_rsq_f64 refined by two Newton steps to full double precision)
+        const double mean = stat_sum(f.stat, C, c) * f.inv_count;
+        double var = stat_sum(f.stat, C, C + c) * f.inv_count - mean * mean;
         if (var < 0) var = 0;
-        const double invstd = 1.0 / sqrt(var + (double)f.eps);
+        const double xv = var + (double)f.eps;
+        double invstd = __builtin_amdgcn_rsq(xv);
+        invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+        invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
         const double sc = (double)f.gamma[c] * invstd;
         k0 = (float)sc; k1 = 0.f; k2 = (float)((double)f.beta[c] - mean * sc);
         if (invstd_out) { *invstd_out = (float)invstd; *xm_out = (float)(-mean * invstd); }   // (= block[LC_INVSTD], block[LC_XM])
@@ -209,7 +214,7 @@ __device__ __forceinline__ void bn_fused_channel(const BnFuse& f, int c, bool wr
     } else {
         const double sdz = stat_sum(f.stat, C, c), sdzx = stat_sum(f.stat, C, C + c);
         const double invstd = f.block[LC_INVSTD * C + c], mean = f.block[LC_MEAN * C + c];
-        const double s = (double)f.gamma[c] * invstd, m1 = sdz / f.count, m2 = sdzx / f.count;
+        const double s = (double)f.gamma[c] * invstd, m1 = sdz * f.inv_count, m2 = sdzx * f.inv_count;
         k0 = (float)s; k1 = (float)(-s * m2 * invstd); k2 = (float)(-s * m1 + s * m2 * mean * invstd);
         if (writer) {
             f.block[LC_P0 * C + c] = k0; f.block[LC_P1 * C + c] = k1; f.block[LC_P2 * C + c] = k2;

@@ -22,16 +22,20 @@ template <typename T> struct DeepConvArgs {
     ConvArgs<T> c;
     int rowp, halfw, imgp, npl;      // LDS patch geometry: pixels per (padded) row, even-column count, pixels per image, pixels in all
     unsigned m_rowp, m_imgp;         // fastdiv magics of rowp / imgp
+    int ablate;                      // diagnostic builds (make STAMPS=1) only: bit 0 no weight DMA after step 0, 1 producers store raw, 2 producers idle
 };
 
 // make STAMPS=1 (diagnostic build): per-wave cycle counters of the kernels below into ConvArgs::dbg, 16 slots per wave:
 //  0 prologue  1 pipeline fill (consumers: interval 0)  2 work (consumers: fragment reads + MFMA; producers: transform + stores)
-//  3 waiting at the step barrier (includes the DMA wait)  4 epilogue  5 whole kernel  6 waiting at the tile-end rendezvous
+//  3 waiting at the step barrier  4 epilogue  5 whole kernel  6 waiting at the tile-end rendezvous  7 setup before the BatchNorm
+//  finalisation  8 consumers: issuing the weight DMA  9 consumers: waiting for their DMA to land
 #ifdef VAE_PHASE_STAMPS
-#define DSTAMP_DECL long long dst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long dst_entry_ = clock64(); long long dst_t_ = dst_entry_;
+#define DABLATE(da_, bit) (((da_).ablate >> (bit)) & 1)
+#define DSTAMP_DECL long long dst_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const long long dst_entry_ = clock64(); long long dst_t_ = dst_entry_;
 #define DSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const long long t1_ = clock64(); dst_[k] += t1_ - dst_t_; dst_t_ = t1_; __builtin_amdgcn_sched_barrier(0); }
-#define DSTAMP_OUT(a_) { if ((a_).dbg && lane == 0) { dst_[5] = clock64() - dst_entry_; for (int k_ = 0; k_ < 8; ++k_) (a_).dbg[((size_t)blockIdx.x * 8 + wave) * 8 + k_] = dst_[k_]; } }
+#define DSTAMP_OUT(a_) { if ((a_).dbg && lane == 0) { dst_[5] = clock64() - dst_entry_; for (int k_ = 0; k_ < 16; ++k_) (a_).dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k_] = dst_[k_]; } }
 #else
+#define DABLATE(da_, bit) 0
 #define DSTAMP_DECL
 #define DSTAMP(k)
 #define DSTAMP_OUT(a_)
@@ -47,8 +51,16 @@ __device__ __forceinline__ int px_off(int j, int q) { return j * PPITCH + (q << 
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // ... and this wave's LDS-DMA copies landed
 __device__ __forceinline__ void barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at the wave-uniform address lds_dst.  Issued through
+// inline asm on purpose: with the builtin (__builtin_amdgcn_global_load_lds) anywhere in the function hipcc (ROCm 7.2) stops
+// counting LDS reads and waits lgkmcnt(0) in front of every MFMA, which exposes the whole LDS latency once per k-step (measured:
+// 290 cycles per k-step of 128 MFMA cycles).  The copies are invisible to the compiler's vmcnt bookkeeping: the issuing wave
+// waits for them itself (barrier_dma).  M0 (the LDS destination) is saved and restored inside the statement.
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+    unsigned keep;
+    const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(l) : "memory");
 }
 }  // namespace deep
 
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
     DSTAMP_DECL
     if (wave >= 4) {
         // =========================== producers ===========================
+        if (DABLATE(da, 3)) __builtin_amdgcn_s_setprio(2);
         const int pt = tid - 256, q = pt & 3;
         // the 12 patch pixels (LDS order) this thread stages for every chunk: j = (pt >> 2) + 64 * slot
         int rel[12], flg[12];   // element offset relative to the tile origin; bit 12 unused slot, 13 top halo, 14 left halo, 15.. image
@@ -119,12 +132,9 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
         TileGeo cur = decode_pair(a, vb, ntiles_n, 32 * NT);
 #pragma unroll
         for (int p = 0; p < 3; ++p) issue_part(p, cur, 0, true);     // chunk 0: in flight during the BatchNorm finalisation below
+        DSTAMP(7)
 
-        if (a.fuse.mode != BNF_NONE) {
-            for (int i = tid; i < Cin; i += 512) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-        } else {
-            for (int i = tid; i < 3 * Cin; i += 512) cf[i] = a.coef[i];
-        }
+        // (the staging coefficients are derived by the consumer half of the workgroup meanwhile: BatchNorm finalisation below)
         deep::barrier_lds();                                          // coefficients published
         DSTAMP(0)
 
@@ -168,14 +178,16 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
             load_coefs(c * CK);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
+                if (!DABLATE(da, 2)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int s = p * 4 + u, j = (pt >> 2) + 64 * s;
-                    Vec16<T> o = xform(R0[p][u], R1[TWO_SRC ? p : 0][TWO_SRC ? u : 0]);
+                    Vec16<T> o = DABLATE(da, 1) ? R0[p][u] : xform(R0[p][u], R1[TWO_SRC ? p : 0][TWO_SRC ? u : 0]);
                     if (!item_ok(cur, flg[s])) o = zero_vec16<T>();
                     *reinterpret_cast<Vec16<T>*>(j < npl ? pb + s * 64 * deep::PPITCH : dummy) = o;
                 }
                 issue_part(p, nxt, cn * CK, nhave);
+                }
                 DSTAMP(2)
                 // the consumers finish a tile in this interval: one more rendezvous (their epilogue borrows the patch half they just read)
                 if (p == 2 && kk >= 1 && c == 0) { deep::barrier_lds(); DSTAMP(6) }
@@ -193,14 +205,24 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
     }
 
     // =========================== consumers ===========================
-    __builtin_amdgcn_s_setprio(1);
+    if (!DABLATE(da, 3)) __builtin_amdgcn_s_setprio(1);
+    // BatchNorm finalisation of the input layer (workgroup 0 also records it): done by the consumers alone, first thing, while the
+    // producers set up their slot tables and get the first chunk's loads in flight
+    if (a.fuse.mode != BNF_NONE) {
+        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    }
+    DSTAMP(7)
     const int wm = wave & 1, wn = wave >> 1, mrow0 = wm * OROWS;
     // weights of K step s (chunk c, tap row ky): 24 pieces of 1 KiB, six per consumer wave
     auto dma_step = [&](int c, int ky, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int id = wave * 6 + i, half = id & 1, kg = (id >> 1) & 3, kx = id >> 3;
-            const uint32_t off = ((uint32_t)((ky * 3 + kx) * (Cin >> 3) + c * 4 + kg) * Cout + n0 + half * 64 + lane) * 16u;
+            int cc = c, kyy = ky;
+            if (DABLATE(da, 4)) { cc = (c + vb) % NCH; kyy = (ky + vb / NCH) % 3; }   // timing experiment: workgroups walk the weights out of phase
+            const uint32_t off = ((uint32_t)((kyy * 3 + kx) * (Cin >> 3) + cc * 4 + kg) * Cout + n0 + half * 64 + lane) * 16u;
             deep::dma16(at_bytes(a.wp, off), wbuf + slot * WSLOT + id * 1024);
         }
     };
@@ -244,12 +266,6 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
     }
     decltype(Vec16<T>::v) prey[EPI == EPI_BWD ? OPL : 1];
 
-    // the producers' BatchNorm finalisation: this half of the workgroup only helps with the channels
-    if (a.fuse.mode != BNF_NONE) {
-        for (int i = tid; i < Cin; i += 512) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-    } else {
-        for (int i = tid; i < 3 * Cin; i += 512) cf[i] = a.coef[i];
-    }
     deep::barrier_lds();
 
     TileGeo cur = decode_pair(a, vb, ntiles_n, 32 * NT);
@@ -265,8 +281,10 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
         for (int p = 0; p < 3; ++p) {
             const int s = 3 * (kk - 1) + p;
             // weights of the next step, into the slot the previous step has just released
-            if (p < 2) dma_step(c, p + 1, (s + 1) & 1);
-            else if (kk < KT) dma_step(c + 1 == NCH ? 0 : c + 1, 0, (s + 1) & 1);
+            if (!DABLATE(da, 0)) {
+                if (p < 2) dma_step(c, p + 1, (s + 1) & 1);
+                else if (kk < KT) dma_step(c + 1 == NCH ? 0 : c + 1, 0, (s + 1) & 1);
+            }
             if constexpr (EPI == EPI_BWD) {
                 if (last_chunk && p == 1) {   // y_out rows of this tile for the epilogue, one interval ahead
                     const int base = ((cur.b0 * a.Hs + cur.y0) * a.Ws + cur.x0) * Cout + n0;
@@ -278,6 +296,7 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
                 }
             }
             const char* wb = wbuf + (s & 1) * WSLOT;
+            DSTAMP(8)
             {
                 Frag<T> af[2][MTW], bf[2][NTW];
                 auto load_frags = [&](int st, int buf) __attribute__((always_inline)) {
@@ -289,14 +308,18 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
                     for (int nt = 0; nt < NTW; ++nt)
                         bf[buf][nt] = load_frag(reinterpret_cast<const T*>(wb + (((kx * 4 + ks * 2 + h) * 128 + (wn * NTW + nt) * 32 + r) << 4)));
                 };
+                // the fragments of k-step st + 1 are requested BEFORE the MFMAs of k-step st (scheduling fences: left to itself the
+                // compiler sinks every read to just in front of its use and exposes the LDS latency twice per k-step)
                 load_frags(0, 0);
 #pragma unroll
                 for (int st = 0; st < 6; ++st) {
                     if (st + 1 < 6) load_frags(st + 1, (st + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MTW; ++mt) mma(acc[mt][nt], af[st & 1][mt], bf[st & 1][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             DSTAMP(2)
@@ -338,6 +361,10 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
                 }
                 DSTAMP(4)
             }
+#ifdef VAE_PHASE_STAMPS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            DSTAMP(9)
+#endif
             deep::barrier_dma();
             DSTAMP(3)
         }
@@ -440,11 +467,7 @@ __global__ __launch_bounds__(512) void up3_kernel(DeepConvArgs<T> da, int n_pair
             chunk_geo(0, g0, c0_); issue_chunk(0, g0, 0, true);
             chunk_geo(KT > 1 ? 1 : 0, g1, c1_); issue_chunk(1, g1, c1_ * CK, KT > 1);
         }
-        if (a.fuse.mode != BNF_NONE) {
-            for (int i = tid; i < Cin; i += 512) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-        } else {
-            for (int i = tid; i < 3 * Cin; i += 512) cf[i] = a.coef[i];
-        }
+        // (the staging coefficients are derived by the consumer half of the workgroup meanwhile: BatchNorm finalisation below)
         deep::barrier_lds();
 
         f32x2 k0[NE / 2], k1[TWO_SRC ? NE / 2 : 1], k2[NE / 2];
@@ -507,6 +530,11 @@ __global__ __launch_bounds__(512) void up3_kernel(DeepConvArgs<T> da, int n_pair
 
     // =========================== consumers ===========================
     __builtin_amdgcn_s_setprio(1);
+    if (a.fuse.mode != BNF_NONE) {
+        for (int i = tid; i < Cin; i += 256) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
+    } else {
+        for (int i = tid; i < 3 * Cin; i += 256) cf[i] = a.coef[i];
+    }
     const int wm = wave & 1, wn = wave >> 1, mrow0 = wm * 64;
     auto dma_chunk = [&](int c, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -554,11 +582,6 @@ __global__ __launch_bounds__(512) void up3_kernel(DeepConvArgs<T> da, int n_pair
     const int py_step = 2 * Ws * Cout;
     decltype(Vec16<T>::v) prey[EPI == EPI_BWD ? OPL : 1];
 
-    if (a.fuse.mode != BNF_NONE) {
-        for (int i = tid; i < Cin; i += 512) bn_fused_channel(a.fuse, i, blockIdx.x == 0, cf[i], cf[Cin + i], cf[2 * Cin + i]);
-    } else {
-        for (int i = tid; i < 3 * Cin; i += 512) cf[i] = a.coef[i];
-    }
     deep::barrier_lds();
 
     TileGeo cur = decode_pair(a, vb, ntiles_n, 64);

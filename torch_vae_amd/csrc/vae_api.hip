@@ -232,6 +232,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_skip_wgrad")) { c->knob_skip_wgrad = value; return 0; }
     if (!strcmp(name, "use_raw_wgrad")) { c->use_raw_wgrad = value; return 0; }
     if (!strcmp(name, "use_deep")) { c->use_deep = value; return 0; }
+    if (!strcmp(name, "use_latent_mfma")) { c->use_latent_mfma = value; return 0; }
     if (!strcmp(name, "knob_fused_grid")) { c->knob_fused_grid = std::max(1, std::min(value, 512)); return 0; }
     if (!strcmp(name, "knob_wgrad_tile")) { c->wk.tile = value; return 0; }
     if (!strcmp(name, "knob_wgrad_wide")) { c->wk.wide = value; return 0; }

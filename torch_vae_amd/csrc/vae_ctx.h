@@ -92,6 +92,12 @@ struct vae_ctx {
     int use_raw_wgrad = 0;
     // use_deep: workgroup-specialised kernels of the deep layers (conv_deep.cuh).  bit 0: stride-2 conv products (dn3), bit 1: transposed products (up3)
     int use_deep = 3;
+    // use_latent_mfma: skinny linears around the latent on the exact-f32 MFMA, one 64-feature tile x the whole batch per workgroup, no batch
+    // split / slabs / reduction launches (latent_mfma.cuh).  Bits: 1 decoder_input forward, 2 its weight + bias gradient, 4 fc_mu|fc_var weight
+    // (+ bias) gradient, 8 fc input gradient.  Measured on MI355X (128x128 L=16 B=256 bf16, isolated): weight gradients 22 / 26 us against
+    // 30 / 28 us + 4 reductions (26 us); the forward (14 vs 12 us) and the fc input gradient (24 vs 22 us) are not faster and stay on the VALU
+    // kernels - whose summation order is also the one the f32 parity gates were measured with.
+    int use_latent_mfma = 6;
     int knob_skip_wgrad = 0;  // diagnostics: bit i skips the separate weight-gradient launch of BN layer i (results wrong, timing only)
     int knob_ablate_f = 0;   // diagnostics: phase ablation of conv_bwd_fused_kernel (timing only)
     // use_fused_convout: a forward with train = 2 (the fused training step) leaves the output conv, sigmoid and BCE to the

@@ -7,6 +7,7 @@
 #include "edge_kernels.cuh"
 #include "conv_fused.cuh"
 #include "conv_deep.cuh"
+#include "latent_mfma.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -59,7 +60,7 @@ static int launch_conv_deep(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
         if (is_down && (size_t)d.npl * 80 < 4 * 64 * 144) return vae_set_error("conv_deep", "patch half smaller than the epilogue tiles");
         if (lds > 160 * 1024) return vae_set_error("conv_deep", "tile does not fit LDS");
         a.dbg = (c->dbg_buf && is_down == !(c->dbg_epi & 16) && c->tag && !strcmp(c->tag, c->dbg_tag) && a.epi == (c->dbg_epi & 15)) ? c->dbg_buf : nullptr;
-        d.c = a;
+        d.c = a; d.ablate = c->knob_ablate_f;
         const double px_lo = (double)a.B * a.Hs * a.Ws, px_hi = 4 * px_lo;
         const double px_in = is_down ? px_hi : px_lo, px_out = is_down ? px_lo : px_hi;
         ProfScope ps(c, is_down ? (a.epi == EPI_FWD ? "down_fwd(conv)" : "down_bwd(convT dgrad)") : (a.epi == EPI_FWD ? "up_fwd(convT)" : "up_bwd(conv dgrad)"),
@@ -334,7 +335,7 @@ static BnFuse make_fuse_fwd(vae_ctx* c, int i, const float* params, float* bn_ru
     f.stat = l.stat_f; f.gamma = params + c->poff[l.p_gamma]; f.beta = params + c->poff[l.p_beta]; f.block = l.block;
     f.running_mean = bn_running ? bn_running + c->bnoff[i] : nullptr; f.running_var = bn_running ? bn_running + c->bnoff[i] + l.C : nullptr;
     f.nbt = nbt ? reinterpret_cast<long long*>(nbt) + i : nullptr;
-    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.eps = kBnEps; f.momentum = kBnMom; f.update_running = bn_running != nullptr;
+    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.inv_count = 1.0 / f.count; f.eps = kBnEps; f.momentum = kBnMom; f.update_running = bn_running != nullptr;
     f.mode = BNF_FWD;
     return f;
 }
@@ -343,7 +344,7 @@ static BnFuse make_fuse_bwd(vae_ctx* c, int i, const float* params, float* grads
     BnFuse f; memset(&f, 0, sizeof(f));
     f.stat = l.stat_b; f.gamma = params + c->poff[l.p_gamma]; f.block = l.block;
     f.dgamma = grads + c->poff[l.p_gamma]; f.dbeta = grads + c->poff[l.p_beta]; f.dconv_bias = grads + c->poff[l.p_convb];
-    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.mode = BNF_BWD; f.ginv = c->ginv;
+    f.C = l.C; f.count = (double)c->B * l.H * l.W; f.inv_count = 1.0 / f.count; f.mode = BNF_BWD; f.ginv = c->ginv;
     return f;
 }
 static int bn_finalize_now(vae_ctx* c, const BnFuse& f, hipStream_t st) {
@@ -384,7 +385,15 @@ int decode_impl(vae_ctx* c, const float* z, int B, const float* params, float* b
     static const char* kLayerTag[8] = {"encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer.0"};
     c->tag = "latent";
     // decoder_input
-    {
+    if (c->use_latent_mfma & 1) {   // 64 feature columns x the whole batch per workgroup on the exact-f32 MFMA (latent_mfma.cuh)
+        RowGemmArgs g; memset(&g, 0, sizeof(g));
+        g.Y = z; g.ldy = L; g.K = L; g.Wf = params + c->poff[20]; g.bias = params + c->poff[21]; g.out = c->d0; g.B = B; g.F = (int)c->F; g.s2 = c->s2;
+        ProfScope ps(c, "decin_fwd", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
+        const size_t lds = row_gemm_lds<T>();
+        if (set_lds(row_gemm_kernel<T, 0>, lds)) return -1;
+        hipLaunchKernelGGL((row_gemm_kernel<T, 0>), dim3((unsigned)(c->F / 64)), dim3(256), lds, st, g);
+        LAUNCH_CHECK("row_gemm_kernel");
+    } else {
         dim3 grid((unsigned)(c->F / 256), (B + 15) / 16);
         ProfScope ps(c, "decin_fwd", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, st);
         hipLaunchKernelGGL((decin_fwd_kernel<T>), grid, dim3(256), 16 * L * 4, st, z, params + c->poff[20], params + c->poff[21],
@@ -760,7 +769,19 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
     // decoder_input backward, reparameterisation + KL backward
     c->tag = "latent";
     {
-        {
+        const bool lat_mfma = (c->use_latent_mfma & 4) && 2 * L <= 9 * 32;   // fc weight gradient path (also produces the bias column sums)
+        if ((c->use_latent_mfma & 2) && L + 1 <= 9 * 32) {   // weight + bias gradient in one launch, no slabs (latent_mfma.cuh)
+            SideFork f = fork_side(c, st);
+            if (f.rc) return f.rc;
+            BatchGemmArgs g; memset(&g, 0, sizeof(g));
+            g.X = c->dd0; g.coef = nullptr; g.slope = 1.f; g.Y = c->z; g.ldy = L; g.ncols = L; g.ones_col = 1;
+            g.out0 = grads + c->poff[20]; g.outb = grads + c->poff[21]; g.B = B; g.F = (int)c->F; g.L = L; g.s2 = c->s2; g.scale = c->ginv;
+            ProfScope ps(c, "decin_wgrad", (double)sizeof(T) * B * (double)c->F + 4.0 * c->F * L, 2.0 * B * c->F * L, f.st);
+            const size_t lds = batch_gemm_lds();
+            if (set_lds(batch_gemm_kernel<T, false>, lds)) return -1;
+            hipLaunchKernelGGL((batch_gemm_kernel<T, false>), dim3((unsigned)(c->F / 64)), dim3(256), lds, f.st, g);
+            LAUNCH_CHECK("batch_gemm_kernel");
+        } else {
             // batch split over grid.z (8 slices) -> slabs -> one reduce per tensor
             const int nz = std::max(1, std::min(8, B / 8)), bsplit = (B + nz - 1) / nz;
             SideFork f = fork_side(c, st);
@@ -785,31 +806,56 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         lb.gmu = g_mu; lb.glv = g_lv; lb.gz = g_z; lb.dlat = c->dlat; lb.B = B; lb.L = L; lb.kld_weight = kld_weight; lb.add_kl = add_kl; lb.gmul = c->gmul;
         hipLaunchKernelGGL(latent_bwd_kernel, dim3((B * L * LAT_LANES + 255) / 256), dim3(256), 0, st, lb);
         LAUNCH_CHECK("latent_bwd_kernel");
+        if (!lat_mfma) {
+            SideFork f = fork_side(c, st);
+            if (f.rc) return f.rc;
+            hipLaunchKernelGGL(colsum_kernel, dim3(2 * L), dim3(64), 0, f.st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L, c->ginv);
+            LAUNCH_CHECK("colsum_kernel");
+        }
+    }
+    // fc_mu / fc_var backward: weight gradients (side stream), then the input gradient with encoder.3's LeakyReLU / BatchNorm prologue
+    if ((c->use_latent_mfma & 4) && 2 * L <= 9 * 32) {
+        // both heads' weight gradients + their bias gradients (column sums of dlat) in one launch, no slabs (latent_mfma.cuh)
         SideFork f = fork_side(c, st);
         if (f.rc) return f.rc;
-        hipLaunchKernelGGL(colsum_kernel, dim3(2 * L), dim3(64), 0, f.st, c->dlat, B, 2 * L, grads + c->poff[17], grads + c->poff[19], L, c->ginv);
-        LAUNCH_CHECK("colsum_kernel");
-    }
-    // fc_mu / fc_var backward
-    {
+        BatchGemmArgs g; memset(&g, 0, sizeof(g));
+        g.X = c->lay[3].y; g.coef = c->lay[3].block; g.slope = kSlope; g.Y = c->dlat; g.ldy = 2 * L; g.ncols = 2 * L; g.ones_col = 0;
+        g.out0 = grads + c->poff[16]; g.out1 = grads + c->poff[18]; g.colsum0 = grads + c->poff[17]; g.colsum1 = grads + c->poff[19];
+        g.B = B; g.F = (int)c->F; g.L = L; g.s2 = c->s2; g.scale = c->ginv;
+        ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
+        const size_t lds = batch_gemm_lds();
+        if (set_lds(batch_gemm_kernel<T, true>, lds)) return -1;
+        hipLaunchKernelGGL((batch_gemm_kernel<T, true>), dim3((unsigned)(c->F / 64)), dim3(256), lds, f.st, g);
+        LAUNCH_CHECK("batch_gemm_kernel");
+    } else {
         FcWgradArgs<T> w;
         w.dlat = c->dlat; w.y = reinterpret_cast<const T*>(c->lay[3].y); w.coef = c->lay[3].block; w.slope = kSlope;
-        w.dwmu = grads + c->poff[16]; w.dwvar = grads + c->poff[18]; w.B = B; w.F = (int)c->F; w.L = L; w.s2 = c->s2;
+        w.B = B; w.F = (int)c->F; w.L = L; w.s2 = c->s2;
+        const int nz = std::max(1, std::min(8, B / 8));
+        w.bsplit = (B + nz - 1) / nz;
+        SideFork f = fork_side(c, st);   // (no new dependency: the side stream is already past latent_bwd)
+        if (f.rc) return f.rc;
+        float* smu = f.slab; float* svar = f.slab + (size_t)nz * L * c->F;
+        w.dwmu = smu; w.dwvar = svar;
         {
-            const int nz = std::max(1, std::min(8, B / 8));
-            w.bsplit = (B + nz - 1) / nz;
-            SideFork f = fork_side(c, st);   // (no new dependency: the side stream is already past latent_bwd)
-            if (f.rc) return f.rc;
-            float* smu = f.slab; float* svar = f.slab + (size_t)nz * L * c->F;
-            w.dwmu = smu; w.dwvar = svar;
-            {
-                ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
-                hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, f.st, w);
-                LAUNCH_CHECK("fc_wgrad_kernel");
-            }
-            if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, f.st, c)) return -1;
-            if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, f.st, c)) return -1;
+            ProfScope ps(c, "fc_wgrad", (double)sizeof(T) * B * (double)c->F + 8.0 * c->F * L, 4.0 * B * c->F * L, f.st);
+            hipLaunchKernelGGL((fc_wgrad_kernel<T>), dim3((unsigned)(c->F / 256), (2 * L + 31) / 32, nz), dim3(256), 0, f.st, w);
+            LAUNCH_CHECK("fc_wgrad_kernel");
         }
+        if (launch_reduce(smu, nz, (size_t)L * c->F, grads + c->poff[16], 0, 0, f.st, c)) return -1;
+        if (launch_reduce(svar, nz, (size_t)L * c->F, grads + c->poff[18], 0, 0, f.st, c)) return -1;
+    }
+    if ((c->use_latent_mfma & 8) && 2 * L <= 256) {
+        RowGemmArgs g; memset(&g, 0, sizeof(g));
+        g.Y = c->dlat; g.ldy = 2 * L; g.K = 2 * L; g.Wp = c->fcpack; g.npad = c->npad_fc; g.out = c->lay[3].dz;
+        g.y = c->lay[3].y; g.ocoef = c->lay[3].block; g.slope = kSlope; g.gpre = g_pre; g.gmul = c->gmul; g.stat = c->lay[3].stat_b;
+        g.B = B; g.F = (int)c->F; g.s2 = c->s2;
+        ProfScope ps2(c, "fc_dgrad", (double)sizeof(T) * (2.0 * B * c->F + 2.0 * c->F * L), 4.0 * B * c->F * L, st);
+        const size_t lds = row_gemm_lds<T>();
+        if (set_lds(row_gemm_kernel<T, 1>, lds)) return -1;
+        hipLaunchKernelGGL((row_gemm_kernel<T, 1>), dim3((unsigned)(c->F / 64)), dim3(256), lds, st, g);
+        LAUNCH_CHECK("row_gemm_kernel");
+    } else {
         FcDgradArgs<T> d;
         d.dlat = c->dlat; d.wp = reinterpret_cast<const T*>(c->fcpack); d.npad = c->npad_fc; d.y = reinterpret_cast<const T*>(c->lay[3].y);
         d.ocoef = c->lay[3].block; d.slope = kSlope; d.gpre = g_pre; d.dz = reinterpret_cast<T*>(c->lay[3].dz); d.stat = c->lay[3].stat_b;

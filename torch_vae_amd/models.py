@@ -591,6 +591,49 @@ class VanillaVAE(nn.Module):
         return out3, xhat
 
 
+    # -- the whole training step as ONE library call ------------------------------------------------------------
+    def fused_train_step(self, optimizer, x: Tensor, eps: Tensor | None = None, use_device_eps: bool = True, exchange: int = 0):
+        """forward -> ELBO -> backward -> [gradient exchange] -> AdamW (train.py:634-656) enqueued by ONE call into the library
+        (include/vae_step.h: vae_train_step_fused) instead of five, with no per-step tensor allocation: the outputs live in
+        buffers owned by the model for the batch size, valid until the next fused step of this model.  ``exchange``: 0 none,
+        1 one RCCL group between backward and AdamW, 2 bucketed (decoder bucket under the encoder backward, each group's AdamW
+        behind its own bucket) - both need the library communicator.  Returns (out3, xhat)."""
+        import ctypes as C
+        self._check_input(x)
+        if not x.is_contiguous() or x.dtype != torch.float32:
+            x = x.detach().contiguous().float()
+        B, L, dev = x.shape[0], self.latent_dim, x.device
+        ctx = self._context(B)
+        if eps is None and not use_device_eps:
+            eps = torch.randn(B, L, device=dev, dtype=torch.float32)
+        if eps is not None:
+            eps = eps.detach().to(dev, torch.float32).contiguous()
+            if eps.shape != (B, L):
+                raise RuntimeError(f"eps must be [{B},{L}]")
+        bufs = self.__dict__.get("_step_bufs")
+        if bufs is None or bufs[0] != (B, dev):
+            bufs = ((B, dev), torch.empty(B, 1, self.img_size, self.img_size, device=dev), torch.empty(B, L, device=dev),
+                    torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(3, device=dev))
+            self.__dict__["_step_bufs"] = bufs
+        _, xhat, mu, lv, z, out3 = bufs
+        self._fwd_count += 1
+        seed = (int(self.eps_seed) + self._fwd_count + _rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        n, offs, sizes, lrs, b1s, beta2, adam_eps, wd = optimizer._step_args()
+        self._bwd_kld_weight = float(self.kld_weight)
+        with self._device_guard():
+            _lib.check(_lib.lib().vae_train_step_fused(
+                ctx.handle, x.data_ptr(), B, self._flat.data_ptr(), self._gflat.data_ptr(), optimizer._m.data_ptr(),
+                optimizer._v.data_ptr(), self._bnflat.data_ptr(), self._nbt.data_ptr(), _lib.ptr(eps), seed, float(self.kld_weight),
+                n, offs, sizes, lrs, b1s, beta2, adam_eps, wd, float(optimizer.grad_scale), optimizer._step + 1, int(exchange),
+                xhat.data_ptr(), mu.data_ptr(), lv.data_ptr(), z.data_ptr(), out3.data_ptr(), self._stream()), "vae_train_step_fused")
+        optimizer._stepped()
+        self._last = dict(x=x, xhat=xhat, mu=mu, lv=lv, z=z, train=True)
+        params, views = self._param_grad_views()
+        if params[0].grad is not views[0] or params[-1].grad is not views[-1]:   # (bound once: the fused path never unbinds them)
+            self.bind_flat_grads()
+        return out3, xhat
+
+
 def count_flops_per_sample(img_size: int, latent_dim: int, generalised: bool = True) -> float:
     """Algorithmic FLOPs of one training step per sample: 3 x 2 x forward MACs."""
     h = img_size

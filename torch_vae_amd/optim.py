@@ -79,6 +79,31 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in g["params"]:
                 self.state[p]["step"] = self._step_t
 
+    def _step_args(self):
+        """(ngroups, offsets, sizes, lrs, beta1s, beta2, eps, weight_decay) of the next update as the C ABI wants them, for
+        the one-call fused step (VanillaVAE.fused_train_step): every group is active there, the gradients being the flat
+        buffer's.  The ctypes arrays are cached; only the two scheduler-driven values per group are refreshed."""
+        self._bind()
+        cache = self.__dict__.get("_arg_cache")
+        n = len(self.param_groups)
+        if cache is None:
+            cache = ((C.c_int64 * n)(*[r[0] for r in self._ranges]), (C.c_int64 * n)(*[r[1] for r in self._ranges]),
+                     (C.c_float * n)(), (C.c_float * n)())
+            self.__dict__["_arg_cache"] = cache
+        offs, sizes, lrs, b1s = cache
+        g0 = self.param_groups[0]
+        for i, g in enumerate(self.param_groups):
+            lrs[i] = g["lr"]; b1s[i] = g["betas"][0]
+            if (g["betas"][1], g["eps"], g["weight_decay"]) != (g0["betas"][1], g0["eps"], g0["weight_decay"]):
+                raise NotImplementedError("groups must share beta2, eps and weight_decay")
+        return n, offs, sizes, lrs, b1s, float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"])
+
+    def _stepped(self):
+        """Bookkeeping of an update the library performed inside vae_train_step_fused."""
+        self._step += 1
+        self._step_t += 1
+        self._opt_called = True   # (torch's schedulers check that the optimiser stepped before them)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None

@@ -125,11 +125,22 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     the encoder half, the encoder bucket following in line; measured here that costs more than the ~40 us it can hide
     (+40..+70 us: a second host call into the backward, two event hand-offs; +0.6 ms in one configuration of hardware
     queues), so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
+    one_call = isinstance(optimizer, FusedAdamW) and os.environ.get("VAE_ONE_CALL_STEP", "1") != "0"
+    if one_call:
+        optimizer._bind()
+        one_call = optimizer._model is model and len(optimizer.param_groups) == len(optimizer._ranges)
     if not _dist_active():
+        if one_call:   # the whole step in one library call (include/vae_step.h: vae_train_step_fused)
+            return model.fused_train_step(optimizer, x, eps=eps, use_device_eps=use_device_eps, exchange=0)
         out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps)
     else:
         if overlap is None:
             overlap = os.environ.get("VAE_DP_OVERLAP", "0") == "1"
+        if one_call:
+            model._context(x.shape[0])   # (creates the context - and with it the library's communicator - on the first step)
+        if one_call and model.library_comm_world() == _dp_world():
+            # data parallel through the library's communicator: in-line group (1) or bucketed exchange (2) inside the same call
+            return model.fused_train_step(optimizer, x, eps=eps, use_device_eps=use_device_eps, exchange=2 if overlap else 1)
         if overlap:
             out3, xhat = model.fused_forward_backward(x, eps=eps, use_device_eps=use_device_eps,
                                                       on_decoder_grads=lambda: _reduce(model, ("decoder",), on_comm_stream=True))
