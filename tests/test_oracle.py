@@ -131,3 +131,33 @@ def test_torch_cpu_port_matches_reference(name):
         x, eps = case_inputs(name, s, np.float32)
         losses.append(st.step(torch.from_numpy(x), torch.from_numpy(eps)))
     np.testing.assert_allclose(np.array(losses), gold["losses"][:len(losses)], rtol=5e-5)
+
+
+def test_storage_emulation_mode():
+    """oracle forward/backward(storage=...) - the checker of the 16-bit kernel modes: identity when off, round-to-nearest-even on the
+    bf16 / f16 grids, gradient-scale aware, and a forward/backward that stays close to the exact one (the 16-bit gap the HIP path
+    itself measures)."""
+    a = np.array([1.0, 1.0 + 2 ** -9, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -3.14159, 1e-30, 65520.0])
+    np.testing.assert_array_equal(vo.round_storage(a, None), a)
+    bf = vo.round_storage(a, "bf16")
+    # bf16 spacing at 1.0 is 2^-7: 1 + 2^-8 is a tie -> even significand (1.0); 1 + 3*2^-8 is a tie -> 1.015625
+    np.testing.assert_array_equal(bf[:4], [1.0, 1.0, 1.0, 1.015625])
+    assert bf[4] == -3.140625
+    np.testing.assert_array_equal(vo.round_storage(a[:5], "f16"), a[:5].astype(np.float16).astype(np.float64))
+    # a value that underflows in f16 survives when stored times the gradient scale
+    assert vo.round_storage(np.array([3e-9]), "f16")[0] == 0.0
+    assert abs(vo.round_storage(np.array([3e-9]), "f16", scale=2.0 ** 20)[0] / 3e-9 - 1) < 1e-3
+    assert vo.f16_grad_scale(256, 128) == 2.0 ** 18 and vo.f16_grad_scale(1, 32) == 2.0 ** 6
+    H, L, B = 32, 8, 3
+    p = vo.init_params(L, H, seed=3)
+    x = vo.synth_pianoroll(B, H, 4).astype(np.float64)
+    eps = vo.counter_normal(B * L, 4, 5).reshape(B, L)
+    c0 = vo.forward(p, x, eps, None, train=True)
+    g0 = vo.backward(p, c0)
+    c1 = vo.forward(p, x, eps, None, train=True, storage=None)
+    assert all(np.array_equal(vo.backward(p, c1)[k], g0[k]) for k in p)
+    for st, tol in (("bf16", 2e-2), ("f16", 3e-3)):
+        cs = vo.forward(p, x, eps, None, train=True, storage=st)
+        assert abs(float(vo.loss(cs)["loss"]) / float(vo.loss(c0)["loss"]) - 1) < tol
+        gsd = vo.backward(p, cs)
+        assert all(np.isfinite(gsd[k]).all() for k in p)

@@ -15,6 +15,14 @@ typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+// Phase-ablation bits of the timing diagnostics (tools/diag/gpu_ablate*.py): compiled in only by `make STAMPS=1`; in the product
+// build the tests fold to constants and the branches disappear from the hot loops.
+#ifdef VAE_PHASE_STAMPS
+#define VAE_ABLATE(word, bits) (((word) & (bits)) != 0)
+#else
+#define VAE_ABLATE(word, bits) false
+#endif
+
 static constexpr int WG_KP = 64;  // weight-gradient kernels: low-res pixels per K tile
 
 #define LDS_PTR(T) T __attribute__((address_space(3)))*

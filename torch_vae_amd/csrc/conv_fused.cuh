@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_fused_kernel(ConvFusedArgs<T>
         int b, y0, x0; tile_origin(t, b, y0, x0);
         __syncthreads();                                   // (A) previous tile fully consumed
         // ---- stage: g patch (BN backward on packed pairs), a_prev patch (BN + LeakyReLU), raw y_prev rows of the output tile
-        if (!(a.ablate & 4)) {
+        if (!VAE_ABLATE(a.ablate, 4)) {
             const int cg0 = (tid & 7) * 8;
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
@@ -569,10 +569,10 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_fused_kernel(ConvFusedArgs<T>
             }
         }
         const int tn = t + (int)gridDim.x;
-        if (!(a.ablate & 8)) issue(tn < a.n_tiles ? tn : t, tn < a.n_tiles);    // next tile's loads fly during the matrix phase
+        if (!VAE_ABLATE(a.ablate, 8)) issue(tn < a.n_tiles ? tn : t, tn < a.n_tiles);    // next tile's loads fly during the matrix phase
         __syncthreads();                                   // (B) patches published
 
-        if (wave < 4 && !(a.ablate & 1)) {
+        if (wave < 4 && !VAE_ABLATE(a.ablate, 1)) {
             // ---- input gradient: 32 low-res pixels x the output parities of this wave's group
             const bool grpB = wq < 2;                       // group B (waves 0,1): classes 0,1,2 (taps 0..4); group A (waves 2,3): class 3 (taps 5..8)
             f32x16 dacc[3];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_fused_kernel(ConvFusedArgs<T>
             if (grpB) { put_class(dacc[0], 0); put_class(dacc[1], 1); put_class(dacc[2], 2); }
             else put_class(dacc[0], 3);
         }
-        if (wave >= 2 && !(a.ablate & 1)) {
+        if (wave >= 2 && !VAE_ABLATE(a.ablate, 1)) {
             // ---- weight gradient: A = g^T (k-major reads of the patch's 64 centre pixels), B = a_prev at the tap's high-res pixels
 #pragma unroll
             for (int j = 0; j < NWT; ++j) {
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_fused_kernel(ConvFusedArgs<T>
         __syncthreads();                                   // (C) accumulator tile complete
         // ---- epilogue in chunk layout: 1024 chunks (16 x 16 pixels x 4 channel quarters), 2 per thread; the tile leaves as 16
         // rows of 1 KiB
-        if (!(a.ablate & 2)) {
+        if (!VAE_ABLATE(a.ablate, 2)) {
             const int qq = tid & 3;
             f32x2 esc2[4], esh2[4];
 #pragma unroll

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
         __syncthreads();
         if (tile + (int)gridDim.x < a.n_tiles) prefetch(tile + gridDim.x);   // in flight during everything below
         // ---- forward tap products: 14 row blocks of 32 patch pixels
-        if (!(a.ablate & 1))
+        if (!VAE_ABLATE(a.ablate, 1))
         for (int mb = wave; mb < NPAD / 32; mb += 4) {
             const int row0 = mb * 32;
             f32x16 acc;
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + 256 * u;
-            if (i < NDL && !(a.ablate & 2)) {
+            if (i < NDL && !VAE_ABLATE(a.ablate, 2)) {
                 const int ry = i / DW, rx = i - ry * DW;
                 float logit = bo;
 #pragma unroll
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acca[mb][i] = 0.f;
-            if (a.ablate & 4) continue;
+            if (VAE_ABLATE(a.ablate, 4)) continue;
             const int ly = 2 * wave + mb, lx = r;
             Frag<T> af;
 #pragma unroll
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
         // ---- dW: K = the wave's 64 pixels, A = a^T (k-major via tr16 from the staged patch), B = dl taps
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (a.ablate & 4) continue;
+            if (VAE_ABLATE(a.ablate, 4)) continue;
             const int k0 = wave * 64 + ks * 16 + 8 * (g4 >> 1) + q;            // tile pixel; k0 + 4 is in the same tile row
             const int row = ((k0 >> 5) + 2) * PW + (k0 & 31) + 2;
             const int col = (16 * (g4 & 1) + 4 * p) * 2;
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
             mma(accw, afr, bfr);
         }
         // ---- epilogue: dz = dA * leaky'(z) written in place over this wave's own y rows
-        if (!(a.ablate & 8))
+        if (!VAE_ABLATE(a.ablate, 8))
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256, 2) void convout_step_mfma_kernel(ConvOutStepAr
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave re-reads only its own 64 pixels
-        if (!(a.ablate & 16))
+        if (!VAE_ABLATE(a.ablate, 16))
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = lane + 64 * u, pix = wave * 64 + (id >> 2), qq = id & 3;

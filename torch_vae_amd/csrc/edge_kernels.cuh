@@ -134,29 +134,35 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
     }
-    constexpr int UNR = 4;   // pixels per thread per trip, all loads issued before use (latency-bound loop)
-    for (int q0 = blockIdx.x * 64 + slot; q0 < P; q0 += gridDim.x * 64 * UNR) {
-        float xv[UNR][9], dv[UNR][8], yv[UNR][8];
+    // A thread takes 4 consecutive output pixels of one row per trip (as conv1_fwd_kernel): their 3x9 input window is two aligned
+    // float4 loads + one scalar per row - 9 load instructions instead of 36 scalar ones (the loop was bound by the issue of its
+    // vector-memory instructions, not by bytes) - and the 4 pixels' dz / y chunks are 8 more 16-byte loads, all in flight together.
+    const int Wq = Wo >> 2, lq = lw - 2, Q = B * Ho * Wq;
+    for (int q = blockIdx.x * 64 + slot; q < Q; q += gridDim.x * 64) {
+        const int oxq = q & (Wq - 1), oy = (q >> lq) & (Ho - 1), b = q >> (lq + lh);
+        const int ix0 = 8 * oxq;
+        float win[3][9], dv[4][8], yv[4][8];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int p = q0 + u * gridDim.x * 64, pc = p < P ? p : 0;
-            const int ox = pc & (Wo - 1), oy = (pc >> lw) & (Ho - 1), b = pc >> (lw + lh);
+        for (int rr = 0; rr < 3; ++rr) {
+            const int iy = 2 * oy + rr - 1;
+            const bool rin = iy >= 0;
+            const float* row = x + ((size_t)b * H + (rin ? iy : 0)) * W + ix0;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(row), v1 = *reinterpret_cast<const f32x4*>(row + 4);
+            const float left = (ix0 > 0) ? row[-1] : 0.f;
+            win[rr][0] = rin ? left : 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-                const bool in = p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float v = x[in ? (b * H + iy) * W + ix : 0];
-                xv[u][t] = in ? v : 0.f;    // pixels beyond the end contribute nothing
-            }
-            load8<T>(dz + (size_t)pc * 32 + cg * 8, dv[u]); load8<T>(y + (size_t)pc * 32 + cg * 8, yv[u]);
+            for (int e = 0; e < 4; ++e) { win[rr][1 + e] = rin ? v0[e] : 0.f; win[rr][5 + e] = rin ? v1[e] : 0.f; }
         }
+        const size_t p0i = ((size_t)b * Ho + oy) * Wo + 4 * oxq;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < 4; ++u) { load8<T>(dz + (p0i + u) * 32 + cg * 8, dv[u]); load8<T>(y + (p0i + u) * 32 + cg * 8, yv[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float g = dv[u][c] * p0[c] + yv[u][c] * p1[c] + p2[c];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[c][t] += g * xv[u][t];
+                for (int t = 0; t < 9; ++t) acc[c][t] += g * win[t / 3][2 * u + t % 3];
             }
         }
     }
@@ -740,26 +746,41 @@ __global__ void pack_kernel(const PackDesc* __restrict__ descs) {
 // ---------------------------------------------------------------------------
 // torch.optim.AdamW (train.py:228) over up to two contiguous parameter ranges
 // (encoder group, decoder group), each with its own OneCycle lr / beta1 (train.py:233-238).
-struct AdamGroup { long off, n; float lr, beta1; };
+struct AdamGroup { long off, n; float lr, beta1; float step_size, inv_sqrt_bc2; };   // step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t): host, in double
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     AdamGroup grp[2]; int ngrp;
     float beta2, eps, weight_decay, grad_scale; int step;
 };
+// One element of torch.optim.AdamW's single-tensor update (decoupled decay, bias corrections as torch computes them).
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamGroup& gr, const AdamArgs& a, float decay) {
+    g *= a.grad_scale;
+    p *= decay;
+    m = m * gr.beta1 + (1.f - gr.beta1) * g;
+    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) * gr.inv_sqrt_bc2 + a.eps;
+    p -= gr.step_size * (m / denom);
+}
+// 16-byte accesses (the flat buffers' ranges start on 256-byte boundaries); a range whose length is not a multiple of four
+// finishes with scalar elements.  The bias corrections arrive as kernel arguments: computed per thread (two f64 pow, a sqrt and a
+// division each) they cost more than the update itself.
 static __global__ void adamw_kernel(AdamArgs a) {
     const AdamGroup gr = a.grp[blockIdx.y];
-    const double bc1 = 1.0 - pow((double)gr.beta1, (double)a.step), bc2 = 1.0 - pow((double)a.beta2, (double)a.step);
-    const float step_size = (float)((double)gr.lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float decay = 1.f - gr.lr * a.weight_decay;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < gr.n; i += (long)gridDim.x * blockDim.x) {
+    const long n4 = (gr.off & 3) == 0 ? gr.n >> 2 : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long k = gr.off + 4 * i;
+        f32x4 p = *reinterpret_cast<const f32x4*>(a.p + k), m = *reinterpret_cast<const f32x4*>(a.m + k), v = *reinterpret_cast<const f32x4*>(a.v + k);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; adamw_one(pe, g[e], me, ve, gr, a, decay); p[e] = pe; m[e] = me; v[e] = ve; }
+        *reinterpret_cast<f32x4*>(a.p + k) = p; *reinterpret_cast<f32x4*>(a.m + k) = m; *reinterpret_cast<f32x4*>(a.v + k) = v;
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < gr.n; i += (long)gridDim.x * blockDim.x) {
         const long k = gr.off + i;
-        const float g = a.g[k] * a.grad_scale;
-        float p = a.p[k] * decay;
-        const float m = a.m[k] * gr.beta1 + (1.f - gr.beta1) * g;
-        const float v = a.v[k] * a.beta2 + (1.f - a.beta2) * g * g;
-        const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
-        p -= step_size * (m / denom);
-        a.p[k] = p; a.m[k] = m; a.v[k] = v;
+        float pe = a.p[k], me = a.m[k], ve = a.v[k];
+        adamw_one(pe, a.g[k], me, ve, gr, a, decay);
+        a.p[k] = pe; a.m[k] = me; a.v[k] = ve;
     }
 }
 

@@ -409,8 +409,13 @@ extern "C" int vae_adamw_step(float* params, const float* grads, float* m, float
     a.p = params; a.g = grads; a.m = m; a.v = v; a.ngrp = ngroups; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
     a.grad_scale = grad_scale; a.step = step;
     long nmax = 0;
-    for (int i = 0; i < ngroups; ++i) { a.grp[i].off = offsets[i]; a.grp[i].n = sizes[i]; a.grp[i].lr = lrs[i]; a.grp[i].beta1 = beta1s[i]; nmax = std::max<long>(nmax, sizes[i]); }
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((nmax + 255) / 256, 2048), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int i = 0; i < ngroups; ++i) {
+        a.grp[i].off = offsets[i]; a.grp[i].n = sizes[i]; a.grp[i].lr = lrs[i]; a.grp[i].beta1 = beta1s[i]; nmax = std::max<long>(nmax, sizes[i]);
+        const double bc1 = 1.0 - pow((double)beta1s[i], (double)step);   // torch.optim.AdamW: bias corrections with the CURRENT (cycled) beta1
+        a.grp[i].step_size = (float)((double)lrs[i] / bc1); a.grp[i].inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((nmax / 4 + 255) / 256 + 1, 2048), ngroups), dim3(256), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK("adamw_kernel");
     return 0;
 }

@@ -90,8 +90,11 @@ struct vae_ctx {
     // side effect by the kernel that stages them first) as plain copies.  Bit-identical; measured 1 % SLOWER in the step on MI355X
     // (the extra stores cost the chain more than the weight-gradient kernels gain: their time is not in the staging arithmetic).
     int use_raw_wgrad = 0;
-    // use_deep: workgroup-specialised kernels of the deep layers (conv_deep.cuh).  bit 0: stride-2 conv products (dn3), bit 1: transposed products (up3)
-    int use_deep = 3;
+    // use_deep: workgroup-specialised kernels of the deep layers (conv_deep.cuh).  bit 0: stride-2 conv products (dn3), bit 1: transposed
+    // products (up3).  Measured on MI355X (128x128 L=16 B=256 bf16, three runs each): dn3 alone 1.262 ms/step, neither 1.267, both 1.279,
+    // up3 alone 1.279 - the transposed kernel's nine LDS-DMA issues per consumer wave and K step (~130 cycles each) cost what its
+    // overlap wins, so it is off by default.
+    int use_deep = 1;
     // use_latent_mfma: skinny linears around the latent on the exact-f32 MFMA, one 64-feature tile x the whole batch per workgroup, no batch
     // split / slabs / reduction launches (latent_mfma.cuh).  Bits: 1 decoder_input forward, 2 its weight + bias gradient, 4 fc_mu|fc_var weight
     // (+ bias) gradient, 8 fc input gradient.  Measured on MI355X (128x128 L=16 B=256 bf16, isolated): weight gradients 22 / 26 us against

@@ -903,7 +903,7 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         BnFuse fb0 = make_fuse_bwd(c, 0, params, grads);
         if (!c->use_fused_bn || !(c->knob_lean & 2)) { if (bn_finalize_now(c, fb0, st)) return -1; fb0.mode = BNF_NONE; }
         const long P = (long)B * (H / 2) * (H / 2);
-        const int grid = (int)std::min<long>((P + 63) / 64, 512);
+        const int grid = (int)std::min<long>((P / 4 + 63) / 64, 512);   // (a thread takes quads of 4 output pixels)
         // last link of the chain: stays on the caller's stream (a side stream would only add an event round trip)
         SideFork f{st, c->slab, 0};
         {
