@@ -227,6 +227,8 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value == 1 ? 3 : (value == 2 ? 1 : (value == 3 ? 2 : 0)); return 0; }   // 1 all, 2 decoder side only, 3 encoder.1 only
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
     if (!strcmp(name, "use_fused_convout")) { c->use_fused_convout = value; return 0; }
+    if (!strcmp(name, "use_convout_stream")) { c->use_convout_stream = value; return 0; }
+    if (!strcmp(name, "knob_convout_bands")) { c->knob_convout_bands = value; return 0; }
     if (!strcmp(name, "knob_convout_step_grid")) { c->knob_convout_step_grid = value > 0 ? value : 1; return 0; }
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }
     if (!strcmp(name, "knob_skip_wgrad")) { c->knob_skip_wgrad = value; return 0; }

@@ -8,6 +8,7 @@
 #include "conv_fused.cuh"
 #include "conv_deep.cuh"
 #include "latent_mfma.cuh"
+#include "convout_stream.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -667,7 +668,30 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
                      ((double)sizeof(T) * (will_recomp ? 32 : 64) + (step7 ? 8.0 : 4.0)) * P, (step7 ? 4.0 : 3.0) * 2 * 9 * 32 * P, st);
         bool launched = false;
         if constexpr (sizeof(T) == 2) {
-            if (step7) {
+            if (step7 && c->use_convout_stream && H == cos::RW) {
+                // row-streaming form: units = (image, band of RB rows); bands only where whole images would leave CUs idle or the
+                // last round mostly empty (a band costs RB/2 + 3 ticks and restages 4 rows)
+                ConvOutStreamArgs<T> m; m.fuse = c->pending_f7;
+                m.yf = reinterpret_cast<const T*>(c->lay[7].y); m.wt = c->wout_t; m.bias = params + c->poff[39]; m.target = c->x;
+                m.xhat = c->xhat; m.accum = c->accum; m.dz = reinterpret_cast<T*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat;
+                m.B = B; m.H = H; m.inv_n = (float)(1.0 / ((double)B * H * H)); m.slope = kSlope; m.gmul = c->gmul;
+                m.dbg = (c->dbg_buf && !strcmp(c->dbg_tag, "final_layer.3")) ? c->dbg_buf : nullptr;
+                const int ncu = 256;
+                long best = -1; int nb = 1;
+                for (int cand = 1; cand <= 16 && H / cand >= 8; cand *= 2) {
+                    const long rounds = ((long)B * cand + ncu - 1) / ncu, cost = rounds * (H / cand / 2 + 3);
+                    if (best < 0 || cost < best) { best = cost; nb = cand; }
+                }
+                if (c->knob_convout_bands > 0 && H % c->knob_convout_bands == 0 && (H / c->knob_convout_bands) % 2 == 0 && H / c->knob_convout_bands >= 8) nb = c->knob_convout_bands;
+                m.nb = nb; m.RB = H / nb; m.n_units = B * nb;
+                grid = std::min(m.n_units, ncu);
+                const size_t lds = convout_stream_lds();
+                if (set_lds(convout_stream_kernel<T>, lds)) return -1;
+                hipLaunchKernelGGL((convout_stream_kernel<T>), dim3(grid), dim3(512), lds, st, m);
+                launched = true;
+                c->convout_pending = 0;
+            }
+            if (step7 && !launched) {
                 ConvOutStepArgs<T> m; m.fuse = c->pending_f7; m.rev = (c->knob_rev >> 1) & 1;
                 m.yf = reinterpret_cast<const T*>(c->lay[7].y); m.wt = c->wout_t; m.bias = params + c->poff[39]; m.target = c->x;
                 m.xhat = c->xhat; m.accum = c->accum; m.dz = reinterpret_cast<T*>(c->lay[7].dz); m.slab = a.slab; m.stat = a.stat;
