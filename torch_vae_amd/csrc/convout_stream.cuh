@@ -23,7 +23,8 @@
 //     Nothing inside a phase depends on another wave's work of the same phase.
 // LDS (155 KiB): y ring 10 rows x 8 KiB and a ring 6 rows x 8 KiB (16-byte chunks XOR-swizzled by (pixel >> 2) & 3: conflict-
 // free b128 fragment reads, b64 transposed reads and b64 epilogue accesses), tap products [4 rows][9][136] f32, dlogit [4 rows]
-// [3 shifted copies][144] 16-bit (a weight-gradient B fragment is one aligned b128 read), targets [8 rows][128] f32.  Ring
+// [3 shifted copies][144] 16-bit, every row stored twice (slots q and q + 4: a consumer's rows base, base-1, base-2 never wrap, so
+// its addresses are a per-lane constant plus one scalar; a weight-gradient B fragment is one aligned b128 read), targets [8 rows][128] f32.  Ring
 // slots follow a running tick counter, not the row number, so consecutive units of a workgroup never collide.
 #pragma once
 #include "conv_mfma.cuh"
@@ -41,12 +42,20 @@ template <typename T> struct ConvOutStreamArgs {
 namespace cos {
 static constexpr int RW = 128, NA = 6, NY = 10, ROWB = RW * 64, PPW = 136, DLW = 144, NTG = 8, RED = 32 * 9 + 64 + 2;
 __device__ __forceinline__ int ring_off(int px, int chunk) { return px * 64 + ((chunk ^ ((px >> 2) & 3)) << 4); }
-// LDS-DMA, 4 B per lane (same M0 protocol as deep::dma16)
+// LDS-DMA, 4 / 16 B per lane (same M0 protocol as deep::dma16).  No "memory" clobber on purpose: the copies read tensors no
+// kernel writes while this one runs and fill ring slots that no compiler-visible access of the same phase touches (the phase
+// barriers, which do clobber memory, order them against the consumers), so the compiler may move LDS reads across them.
 __device__ __forceinline__ void dma4(const void* gsrc, char* lds_dst) {
     unsigned keep;
     const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(l) : "memory");
+                 : "=&s"(keep) : "v"(gsrc), "s"(l));
+}
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst) {
+    unsigned keep;
+    const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(l));
 }
 // at most n of this wave's vector-memory operations still outstanding (they complete in issue order)
 __device__ __forceinline__ void wait_vm(int n) {
@@ -64,7 +73,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 }
 }
 static inline size_t convout_stream_lds() {
-    return (size_t)(cos::NY + cos::NA) * cos::ROWB + 4 * 9 * cos::PPW * 4 + 4 * 3 * cos::DLW * 2 + cos::NTG * cos::RW * 4 + 128 * 4;
+    return (size_t)(cos::NY + cos::NA) * cos::ROWB + 4 * 9 * cos::PPW * 4 + 8 * 3 * cos::DLW * 2 + cos::NTG * cos::RW * 4 + 128 * 4;
 }
 
 template <typename T>
@@ -72,21 +81,22 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
     using namespace cos;
     typedef typename H16<T>::v8 T8;
     typedef typename H16<T>::v2 T2;
+    typedef __attribute__((ext_vector_type(4))) T T4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* yring = smem;                                                    // raw y (dz in place), filled by LDS-DMA
     char* aring = yring + NY * ROWB;                                       // a = LeakyReLU(BN(y))
     float* part = reinterpret_cast<float*>(aring + NA * ROWB);             // [4][9][PPW], pixel x at index x + 4
-    T* dlc = reinterpret_cast<T*>(part + 4 * 9 * PPW);                     // [4][3][DLW], copy c at index i + 8 holds dl[i - c + 1]
-    float* tgr = reinterpret_cast<float*>(dlc + 4 * 3 * DLW);              // [NTG][RW] targets, filled by LDS-DMA
+    T* dlc = reinterpret_cast<T*>(part + 4 * 9 * PPW);                     // [8][3][DLW], copy c at index i + 8 holds dl[i - c + 1]; row q also at q + 4
+    float* tgr = reinterpret_cast<float*>(dlc + 8 * 3 * DLW);              // [NTG][RW] targets, filled by LDS-DMA
     float* cf = tgr + NTG * RW;                                            // scale | shift | invstd | -mean*invstd
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-    const int H = a.H, G = gridDim.x;
+    const int H = a.H, G = gridDim.x, K = a.RB / 2 + 3;
     DSTAMP_DECL
 
     if (tid < 32) { float k1; bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], k1, cf[32 + tid], &cf[64 + tid], &cf[96 + tid]); }
     for (int i = tid; i < 4 * 9 * PPW; i += 512) part[i] = 0.f;
-    for (int i = tid; i < 4 * 3 * DLW / 2; i += 512) reinterpret_cast<int*>(dlc)[i] = 0;
+    for (int i = tid; i < 8 * 3 * DLW / 2; i += 512) reinterpret_cast<int*>(dlc)[i] = 0;
     Frag<T> wfA[2];      // tap products: A[m = tap r][k = channel]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -105,48 +115,68 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
     for (int i = 0; i < 16; ++i) accw[i] = 0.f;
 
     const int brow = wave >> 2, x0 = (wave & 3) * 32;     // phase 2: this wave's block (also: the quarter row its copies fill)
-    const int lrow = tid >> 7, lx = tid & 127;            // phase 1 (threads 0..255): this thread's logit pixel
-    const int srow_lds = (tid & 511) * 16;                // staging: this thread's chunk of both rows (linear = swizzled position)
+    const int lrow = wave >> 1, lx = tid & 127;           // phase 1, waves 0..3: this thread's logit pixel
+    // ---- per-lane address constants (bytes), so that a tick adds one scalar to each
+    // dA's B fragment, element j: tap 8h + j of pixel x0 + r from copy 1 of dl row (base - ky); taps >= 9 read a cell that stays zero
+    int offA[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 8 * h + j, ky = t / 3, kx = t - 3 * ky;
+        offA[j] = t < 9 ? ((-ky * 3 + 1) * DLW + x0 + r - kx + 1 + 8) * 2 : 0;
+    }
+    // dW's B fragment: 8 pixels x0 + 8h .. of copy kx of dl row (base - ky), tap = min(r, 8) (columns >= 9 of dW are never read)
+    const int tW = r < 9 ? r : 8, kyW = tW / 3, kxW = tW - 3 * kyW;
+    const int offW = ((-kyW * 3 + kxW) * DLW + x0 + 8 * h + 8) * 2;
+    // dW's A fragment (transposed reads of the a ring) and the block's b128 / b64 cells
+    const int pxa = x0 + 8 * (g4 >> 1) + q, chA = 2 * (g4 & 1) + (p >> 1);
+    const int offT0 = ring_off(pxa, chA) + (p & 1) * 8, offT1 = ring_off(pxa + 4, chA) + (p & 1) * 8;   // (+1024: the second k-step, same swizzle)
+    const int offB0 = ring_off(x0 + r, h), offB1 = ring_off(x0 + r, 2 + h);                             // tap products: channels 8h.., 16 + 8h..
+    const int offE = (x0 + r) * 64 + 8 * h, swz = (((x0 + r) >> 2) & 3) << 4;                            // epilogue cell of chunk g: offE + ((g << 4) ^ swz)
+    const int offS0 = ring_off(x0 + (lane >> 2), lane & 3), offS1 = ring_off(x0 + 16 + (lane >> 2), lane & 3);   // dz store
+    const int offP = ((4 * h) * PPW + 4 + x0 + r) * 4;                                                  // tap products of taps 4h ..
+
     // LDS-DMA of one tick: y rows s, s+1 of image b into y-ring slots ys, ys+1 (wave: row `brow`, quarter `wave & 3`, two 1 KiB
     // copies; lane i of a copy fetches the chunk stored at linear position i), targets of logit rows s-3, s-2 into target slots
     // ts0, ts0+1 (waves 0..3: row wave >> 1, half wave & 1).  Rows outside the image or the band's needs copy row 0 (never used).
-    auto issue = [&](int b, int r0, int r1, int s, int ys, int ts0) __attribute__((always_inline)) {
-        if (wave < 4) {
-            const int row = s - 3 + (wave >> 1);
-            const bool ok = row >= 0 && row < H && row >= r0 - 1 && row <= r1;
-            const float* src = a.target + ((size_t)(b * H + (ok ? row : 0))) * RW + (wave & 1) * 64 + lane;
-            int ts = ts0 + (wave >> 1); ts = ts >= NTG ? ts - NTG : ts;
-            dma4(src, reinterpret_cast<char*>(tgr + ts * RW + (wave & 1) * 64));
-        }
-        const int row = s + brow;
-        const bool ok = row >= 0 && row < H && row <= r1 + 1;
-        const char* rowp = reinterpret_cast<const char*>(a.yf + ((size_t)(b * H + (ok ? row : 0)) * RW) * 32);
-        int slot = ys + brow; slot = slot >= NY ? slot - NY : slot;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ci = (wave & 3) * 128 + j * 64 + lane, px = ci >> 2, ch = (ci & 3) ^ ((px >> 2) & 3);
-            deep::dma16(rowp + px * 64 + ch * 16, yring + slot * ROWB + ((wave & 3) * 128 + j * 64) * 16);
-        }
-    };
-    // the tick two ahead of the one being worked on: (unit, k) and ring positions
-    int ua = blockIdx.x, ka = 0, ya = 0, ta = 5;        // target slot of logit row s-3 of tick g = (2g + 5) % 8
+    const int dci = (wave & 3) * 128 + lane, dpx = dci >> 2;
+    const int dsrc0 = dpx * 64 + (((dci & 3) ^ ((dpx >> 2) & 3)) << 4);            // source byte offset in the row, first copy (second: + 1024)
+    int ua = blockIdx.x, ka = 0, ya = 0, ta = 5;        // the tick two ahead: unit, tick, y slot of its row s, target slot of its logit row s-3
+    int ba = 0, r0a = 0;
+    if (ua < a.n_units) { ba = ua / a.nb; r0a = (ua - ba * a.nb) * a.RB; }
     const int nD = wave < 4 ? 3 : 2;                    // copies per tick of this wave
     auto issue_ahead = [&]() __attribute__((always_inline)) {   // returns the number of copies this wave issued
         const bool live = ua < a.n_units;
         if (live) {
-            const int b = ua / a.nb, r0 = (ua - b * a.nb) * a.RB;
-            issue(b, r0, r0 + a.RB, r0 - 2 + 2 * ka, ya, ta);
+            const int s = r0a - 2 + 2 * ka, r1 = r0a + a.RB;
+            if (wave < 4) {
+                const int row = s - 3 + (wave >> 1);
+                const bool ok = row >= 0 && row < H && row >= r0a - 1 && row <= r1;
+                const float* src = a.target + ((size_t)(ba * H + (ok ? row : 0))) * RW + (wave & 1) * 64 + lane;
+                const int ts = (ta + (wave >> 1)) & (NTG - 1);
+                dma4(src, reinterpret_cast<char*>(tgr + ts * RW + (wave & 1) * 64));
+            }
+            const int row = s + brow;
+            const bool ok = row >= 0 && row < H && row <= r1 + 1;
+            const char* rowp = reinterpret_cast<const char*>(a.yf + ((size_t)(ba * H + (ok ? row : 0)) * RW) * 32) + dsrc0;
+            int slot = ya + brow; slot = slot >= NY ? slot - NY : slot;
+            char* dst = yring + slot * ROWB + (wave & 3) * 2048;
+            dma16(rowp, dst);
+            dma16(rowp + 1024, dst + 1024);
         }
         ya = ya + 2 >= NY ? ya + 2 - NY : ya + 2; ta = (ta + 2) & (NTG - 1);
-        if (++ka == a.RB / 2 + 3) { ka = 0; ua += G; }
+        if (++ka == K) {
+            ka = 0; ua += G;
+            if (ua < a.n_units) { ba = ua / a.nb; r0a = (ua - ba * a.nb) * a.RB; }
+        }
         return live ? nD : 0;
     };
     issue_ahead();
     const int nd1 = issue_ahead();
     deep::barrier_lds();                 // cf published, borders zeroed
-    f32x2 kc[4], kh[4];                  // staging: this thread's 8 channels
+    f32x2 kc[4], kh[4];                  // staging (waves 4..7): the 8 channels of this thread's four chunks
+    const int st = tid & 255, spos = st * 16;                               // chunks st, st + 256 of rows s and s + 1 (linear = swizzled position)
     {
-        const int px = (tid >> 2) & 127, ch = (tid & 3) ^ ((px >> 2) & 3);   // the chunk at this thread's linear position
+        const int px = st >> 2, ch = (st & 3) ^ ((px >> 2) & 3);            // (pixel + 64 has the same swizzle)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             kc[e] = f32x2{cf[ch * 8 + 2 * e], cf[ch * 8 + 2 * e + 1]};
@@ -168,30 +198,41 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
     int nz_prev = 0;                     // dz stores of the previous tick (vmcnt bookkeeping)
     for (int unit = blockIdx.x; unit < a.n_units; unit += G) {
         const int b = unit / a.nb, r0 = (unit - b * a.nb) * a.RB, r1 = r0 + a.RB;
-        const int K = a.RB / 2 + 3;
         for (int k = 0; k < K; ++k) {
             const int s = r0 - 2 + 2 * k;
             int nx = 0;
             // ================= phase 1 =================
+            if (wave >= 4) {
+                // stage rows s, s + 1: y ring -> BatchNorm + LeakyReLU -> a ring
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int row = s + u;
-                const bool ok = row >= 0 && row < H && row <= r1 + 1;
-                int ys = py + u; ys = ys >= NY ? ys - NY : ys;
-                int as = pa + u; as = as >= NA ? as - NA : as;
-                const T8 yv = *reinterpret_cast<const T8*>(yring + ys * ROWB + srow_lds);
-                T8 o;
+                for (int u = 0; u < 2; ++u) {
+                    const int row = s + u;
+                    const bool ok = row >= 0 && row < H && row <= r1 + 1;
+                    int ys = py + u; ys = ys >= NY ? ys - NY : ys;
+                    int as = pa + u; as = as >= NA ? as - NA : as;
+                    const char* ysrc = yring + ys * ROWB + spos;
+                    char* adst = aring + as * ROWB + spos;
+                    if (!ok) {     // (wave-uniform) outside the image: a = 0
+                        *reinterpret_cast<T8*>(adst) = T8{0, 0, 0, 0, 0, 0, 0, 0}; *reinterpret_cast<T8*>(adst + 4096) = T8{0, 0, 0, 0, 0, 0, 0, 0};
+                        continue;
+                    }
+                    const T8 yv0 = *reinterpret_cast<const T8*>(ysrc), yv1 = *reinterpret_cast<const T8*>(ysrc + 4096);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f32x2 z = f32x2{(float)yv[2 * e], (float)yv[2 * e + 1]} * kc[e] + kh[e];
-                    const f32x2 zs = z * a.slope;
-                    z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
-                    o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
+                    for (int v = 0; v < 2; ++v) {
+                        const T8 yv = v ? yv1 : yv0;
+                        T8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            f32x2 z = f32x2{(float)yv[2 * e], (float)yv[2 * e + 1]} * kc[e] + kh[e];
+                            const f32x2 zs = z * a.slope;
+                            z.x = fmaxf(z.x, zs.x); z.y = fmaxf(z.y, zs.y);
+                            o[2 * e] = (T)z.x; o[2 * e + 1] = (T)z.y;
+                        }
+                        *reinterpret_cast<T8*>(adst + v * 4096) = o;
+                    }
                 }
-                if (!ok) o = T8{0, 0, 0, 0, 0, 0, 0, 0};
-                *reinterpret_cast<T8*>(aring + as * ROWB + srow_lds) = o;
-            }
-            if (wave < 4) {
+            } else {
+                // logits / sigmoid / BCE / dlogit of rows s - 3, s - 2 (a wave = half a row)
                 const int R = s - 3 + lrow;
                 const bool ok = R >= 0 && R < H && R >= r0 - 1 && R <= r1;
                 const float tg = tgr[((p8 + lrow) & (NTG - 1)) * RW + lx];
@@ -205,7 +246,8 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
                 const T dlt = (T)dl;
                 T* drow = dlc + ((p4 + 1 + lrow) & 3) * 3 * DLW + lx + 8;
                 drow[-1] = dlt; drow[DLW] = dlt; drow[2 * DLW + 1] = dlt;
-                if (ok && R >= r0 && R < r1) {        // the band's own rows (wave-uniform: a wave = half a row)
+                drow[12 * DLW - 1] = dlt; drow[13 * DLW] = dlt; drow[14 * DLW + 1] = dlt;      // the same row at slot + 4
+                if (ok && R >= r0 && R < r1) {        // the band's own rows
                     const float l1 = fmaxf(logf(xh), -100.f), l0 = fmaxf(logf(1.f - xh), -100.f);
                     bsum += -(tg * l1 + (1.f - tg) * l0);
                     a.xhat[((size_t)(b * H + R)) * RW + lx] = xh;
@@ -220,23 +262,30 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
             const int nd = issue_ahead();
             {   // tap products of a row s + brow
                 int as = pa + brow; as = as >= NA ? as - NA : as;
+                const char* arow_ = aring + as * ROWB;
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    Frag<T> bf = load_frag(reinterpret_cast<const T*>(aring + as * ROWB + ring_off(x0 + r, 2 * ks + h)));
-                    mma(acc, wfA[ks], bf);
-                }
-                float* pr = part + ((p4 + brow) & 3) * 9 * PPW + 4 + x0 + r;
-                if (h == 0) { pr[0] = acc[0]; pr[PPW] = acc[1]; pr[2 * PPW] = acc[2]; pr[3 * PPW] = acc[3]; pr[8 * PPW] = acc[4]; }
-                else { pr[4 * PPW] = acc[0]; pr[5 * PPW] = acc[1]; pr[6 * PPW] = acc[2]; pr[7 * PPW] = acc[3]; }
+                Frag<T> b0 = load_frag(reinterpret_cast<const T*>(arow_ + offB0)), b1 = load_frag(reinterpret_cast<const T*>(arow_ + offB1));
+                mma(acc, wfA[0], b0);
+                mma(acc, wfA[1], b1);
+                float* pr = reinterpret_cast<float*>(reinterpret_cast<char*>(part + ((p4 + brow) & 3) * 9 * PPW) + offP);
+                pr[0] = acc[0]; pr[PPW] = acc[1]; pr[2 * PPW] = acc[2]; pr[3 * PPW] = acc[3];     // taps 4h .. 4h + 3
+                if (h == 0) pr[8 * PPW] = acc[4];                                                 // tap 8
             }
             const int Rf = s - 4 + brow;
             int nz = 0;
             if (Rf >= r0 && Rf < r1) {
                 int as = pa + 2 + brow; as = as >= NA ? as - NA : as;            // a ring slot of row s - 4 + brow
                 int ys = py + NY - 4 + brow; ys = ys >= NY ? ys - NY : ys;       // y ring slot of the same row
+                const char* arow_ = aring + as * ROWB;
+                char* yrow = yring + ys * ROWB;
+                // dl row Rf + 1 (tap row 0) sits at logical slot p4 + 1 + brow + 1 - 1; its mirrored slot in 4..7 never wraps going down
+                const char* dbase = reinterpret_cast<const char*>(dlc + (4 + ((p4 + 1 + brow) & 3)) * 3 * DLW);
+                // ---- the block's y (epilogue), issued first
+                T4 yq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yq[g] = *reinterpret_cast<const T4*>(yrow + offE + ((g << 4) ^ swz));
                 // ---- dA[channel][pixel] = sum_t w[t][channel] dl[pixel - t]
                 f32x16 acca;
 #pragma unroll
@@ -244,64 +293,46 @@ __global__ __launch_bounds__(512) void convout_stream_kernel(ConvOutStreamArgs<T
                 {
                     Frag<T> bf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int t = 8 * h + j, tt = t < 9 ? t : 0;     // (h == 1: tap 8, then zeros)
-                        // dl row Rf - ky + 1 = s - 3 + (brow - ky): ring slot p4 + 1 + brow - ky
-                        const T v = dlc[(((p4 + 5 + brow - tt / 3) & 3) * 3 + 1) * DLW + x0 + r - tt % 3 + 1 + 8];
-                        bf.v[j] = t < 9 ? v : (T)0.f;
-                    }
+                    for (int j = 0; j < 8; ++j) bf.v[j] = *reinterpret_cast<const T*>(dbase + offA[j]);
                     mma(acca, wfT, bf);
                 }
                 // ---- dW[channel][tap] += sum_pixels a[pixel][channel] dl[pixel - tap]
-                const int tt = r < 9 ? r : 8, ky = tt / 3, kx = tt - 3 * ky;
-                const T* drow = dlc + (((p4 + 5 + brow - ky) & 3) * 3 + kx) * DLW + x0 + 8 * h + 8;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const int pxa = x0 + ks * 16 + 8 * (g4 >> 1) + q;
-                    const int chunk = 2 * (g4 & 1) + (p >> 1), within = (p & 1) * 8;
-                    const char* arow_ = aring + as * ROWB;
-                    Frag<T> afr = frag_tr16<T>(arow_ + ring_off(pxa, chunk) + within, arow_ + ring_off(pxa + 4, chunk) + within);
-                    Frag<T> bfr = load_frag(drow + ks * 16);
+                    Frag<T> afr = frag_tr16<T>(arow_ + offT0 + ks * 1024, arow_ + offT1 + ks * 1024);
+                    Frag<T> bfr = load_frag(reinterpret_cast<const T*>(dbase + offW + ks * 32));
                     mma(accw, afr, bfr);
                 }
                 // ---- epilogue: dz = dA * leaky'(z), in place over y (this lane: pixel x0 + r, channels 8g + 4h .. + 3)
-                char* yrow = yring + ys * ROWB;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    char* cell = yrow + ring_off(x0 + r, g) + 8 * h;
-                    const T2 y01 = *reinterpret_cast<const T2*>(cell), y23 = *reinterpret_cast<const T2*>(cell + 4);
-                    T2 o01, o23;
+                    T4 o4;
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {
                         const int e = 2 * g + e2;
-                        const T2 yy = e2 ? y23 : y01;
-                        const f32x2 yv = f32x2{(float)yy[0], (float)yy[1]};
+                        const f32x2 yv = f32x2{(float)yq[g][2 * e2], (float)yq[g][2 * e2 + 1]};
                         const f32x2 z = f32x2{__builtin_fmaf(yv.x, esc[e].x, esh[e].x), __builtin_fmaf(yv.y, esc[e].y, esh[e].y)};
                         const float d0 = acca[4 * g + 2 * e2], d1 = acca[4 * g + 2 * e2 + 1];
-                        T2 o;
-                        o[0] = (T)(z.x > 0.f ? d0 : d0 * a.slope); o[1] = (T)(z.y > 0.f ? d1 : d1 * a.slope);
-                        const f32x2 dzv = f32x2{(float)o[0], (float)o[1]};
+                        const T o0 = (T)(z.x > 0.f ? d0 : d0 * a.slope), o1 = (T)(z.y > 0.f ? d1 : d1 * a.slope);
+                        const f32x2 dzv = f32x2{(float)o0, (float)o1};
                         s1[e] += dzv;
                         s2[e] = f32x2{__builtin_fmaf(dzv.x, yv.x, s2[e].x), __builtin_fmaf(dzv.y, yv.y, s2[e].y)};   // sum dz*y (see the reduction)
-                        if (e2) o23 = o; else o01 = o;
+                        o4[2 * e2] = o0; o4[2 * e2 + 1] = o1;
                     }
-                    *reinterpret_cast<T2*>(cell) = o01; *reinterpret_cast<T2*>(cell + 4) = o23;
+                    *reinterpret_cast<T4*>(yrow + offE + ((g << 4) ^ swz)) = o4;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave re-reads only its own 32 pixels
-                T* drow_g = a.dz + ((size_t)(b * H + Rf) * RW + x0) * 32;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int px = (lane >> 2) + 16 * u, ch = lane & 3;
-                    const T8 v = *reinterpret_cast<const T8*>(yrow + ring_off(x0 + px, ch));
-                    *reinterpret_cast<T8*>(drow_g + px * 32 + ch * 8) = v;
-                }
+                // (the wave re-reads only its own 32 pixels: LDS executes a wave's accesses in order, no wait needed)
+                char* dg = reinterpret_cast<char*>(a.dz + ((size_t)(b * H + Rf) * RW + x0) * 32) + lane * 16;
+                const T8 v0 = *reinterpret_cast<const T8*>(yrow + offS0), v1 = *reinterpret_cast<const T8*>(yrow + offS1);
+                *reinterpret_cast<T8*>(dg) = v0;
+                *reinterpret_cast<T8*>(dg + 1024) = v1;
                 nz = 2;
             }
             DSTAMP(3)
             // vector-memory operations of this wave since the copies of the NEXT tick were issued (phase 2 of the previous tick):
             // that tick's dz stores, this tick's xhat store, this tick's copies, this tick's dz stores - the next tick's copies
             // must have landed, everything younger may stay in flight
-            wait_vm(nz_prev + nx + nd + nz);
+            wait_vm(__builtin_amdgcn_readfirstlane(nz_prev + nx + nd + nz));
             nz_prev = nz;
             deep::barrier_lds();
             DSTAMP(4)
