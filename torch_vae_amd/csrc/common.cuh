@@ -24,6 +24,13 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 #endif
 
 static constexpr int WG_KP = 64;  // weight-gradient kernels: low-res pixels per K tile
+#ifndef WG_SPAD_V
+#define WG_SPAD_V 64
+#endif
+#ifndef WG_GPAD_V
+#define WG_GPAD_V 32
+#endif
+static constexpr int WG_SPAD = WG_SPAD_V, WG_GPAD = WG_GPAD_V;  // row pads (bytes) of the staged low-res / high-res operand
 
 #define LDS_PTR(T) T __attribute__((address_space(3)))*
 

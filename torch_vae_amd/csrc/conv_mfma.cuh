@@ -382,7 +382,11 @@ __global__ __launch_bounds__(64 * NW, ((sizeof(T) == 2 && WA * WB < 4 && NW == 4
     constexpr int NTHR = 64 * NW, SIT = WG_KP * 4 * WA / NTHR;   // threads; low-res chunks per thread
     constexpr int TS = NW / (WA * WB), NTW = (9 + TS - 1) / TS, E16 = 16 / sizeof(T);
     constexpr int SROW = 32 * WA * sizeof(T), GROW = 32 * WB * sizeof(T);
-    constexpr int SPITCH = SROW + 16, GPITCH = GROW + 16;
+    // row pitches of the two staged operands: the transposed reads of a lane group touch 4 pixel rows x 32..64 B - consecutive rows
+    // of the low-res tile, every second row of the high-res patch - and must land on distinct banks (pitch = 16 dwords mod 64 for
+    // the former, 2 * pitch = 16 or 48 dwords mod 64 for the latter); with the 16-byte pads of round 2 half of the LDS cycles of this
+    // kernel were bank conflicts (profiles/r02_pmc_sq_v2.txt)
+    constexpr int SPITCH = SROW + WG_SPAD, GPITCH = GROW + WG_GPAD;
     constexpr int SCH = SROW / 16, GCH = GROW / 16;  // 16-byte chunks per staged pixel
     constexpr bool S_TWO = !CONVT && !RAW, G_TWO = CONVT && !RAW;
     constexpr int MAXG = (5 * WB * 256 + NTHR - 1) / NTHR;

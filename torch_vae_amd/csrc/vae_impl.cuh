@@ -243,8 +243,8 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     a.m_pp = fastdiv_magic((2 * th + 1) * (2 * tw + 1)); a.m_pw = fastdiv_magic(2 * tw + 1); a.m_tx = fastdiv_magic(t.tiles_x); a.m_txy = fastdiv_magic(t.tiles_x * t.tiles_y);
     const bool mid8 = c->wk.mid8 && WA == 2 && WB == 1 && pre;   // eight waves on the 64x32-channel tile
     const int nthr = (WA == 4 || mid8) ? 512 : 256, maxg = (5 * WB * 256 + nthr - 1) / nthr;
-    const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + 16) +
-                       (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + 16) +
+    const size_t lds = (size_t)(3 * 32 * WA + 3 * 32 * WB) * 4 + (size_t)WG_KP * (32 * WA * sizeof(T) + WG_SPAD) +
+                       (size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) + WG_GPAD) +
                        (pre ? std::max<size_t>((size_t)TB * (2 * th + 1) * (2 * tw + 1) * (32 * WB * sizeof(T) / 16), (size_t)maxg * nthr) * 8 : 0);   // + staging table (prefetching variants, padded to MAXG*threads)
     dim3 grid(nsplit, a.CA / (32 * WA), a.CB / (32 * WB));
     const double px_s = (double)a.B * a.Hs * a.Ws;
@@ -687,7 +687,7 @@ static int backward_first(vae_ctx* c, const float* x, const float* params, float
                 grid = std::min(m.n_units, ncu);
                 const size_t lds = convout_stream_lds();
                 if (set_lds(convout_stream_kernel<T>, lds)) return -1;
-                hipLaunchKernelGGL((convout_stream_kernel<T>), dim3(grid), dim3(512), lds, st, m);
+                hipLaunchKernelGGL((convout_stream_kernel<T>), dim3(grid), dim3(1024), lds, st, m);
                 launched = true;
                 c->convout_pending = 0;
             }
