@@ -614,7 +614,14 @@ def test_full_size_properties(dtype):
     m2 = make_model(H, L, gen, dtype, p, kld_weight=4.0)
     m2.set_next_eps(eps)
     (2.0 * m2.loss(m2(x))["loss"]).backward()
-    assert torch.equal(m2.flat_grads(), 2.0 * g1)
+    if dtype != "f32" and H == 128:
+        # (the one-pass step takes the row-streaming output-conv kernel, the autograd path the tiled kernels: their BatchNorm-
+        #  backward statistics differ in the last f32 bits, which moves a few 16-bit roundings upstream)
+        lin = rel_l2(m2.flat_grads().cpu().numpy(), 2.0 * g1.cpu().numpy())
+        report(test="full_size_properties_linearity", dtype=dtype, rel_l2=lin)
+        assert lin < {"bf16": 5e-4, "f16": 2e-4}[dtype], lin   # (measured 2.4e-5 at bf16)
+    else:
+        assert torch.equal(m2.flat_grads(), 2.0 * g1)
     # batch permutation
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
     m3 = make_model(H, L, gen, dtype, p, kld_weight=4.0)
@@ -779,7 +786,11 @@ def test_full_size_baseline_configs(cfg):
     m2.set_next_eps(eps)
     (2.0 * m2.loss(m2(x))["loss"]).backward()
     if dtype == "f16":
-        assert rel_l2(m2.flat_grads().cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-4
+        assert rel_l2(m2.flat_grads().cpu().numpy(), 2.0 * g1.cpu().numpy()) < 2e-4
+    elif dtype == "bf16" and H == 128:    # (row-streaming vs tiled output-conv kernel: statistics summed in another order)
+        lin = rel_l2(m2.flat_grads().cpu().numpy(), 2.0 * g1.cpu().numpy())
+        report(test="full_size_baseline_linearity", dtype=dtype, cfg=[H, L, B], rel_l2=lin)
+        assert lin < 5e-4, lin   # (measured 2.4e-5)
     else:
         assert torch.equal(m2.flat_grads(), 2.0 * g1)
     del m2
@@ -1092,6 +1103,9 @@ def test_fused_dgrad_wgrad_matches_separate_kernels(cfg):
         model._context(B)
         assert _lib.lib().vae_set_option(model._ctx.handle, b"use_fused_wgrad", use) == 0
         assert _lib.lib().vae_set_option(model._ctx.handle, b"use_recomp_dz", recomp) == 0
+        # (bit-identity across these variants needs the same BatchNorm-backward statistics in all of them: the row-streaming
+        #  output-conv kernel sums them in another order than the tiled kernels the recomputing variant runs)
+        assert _lib.lib().vae_set_option(model._ctx.handle, b"use_convout_stream", 0) == 0
         out3, _ = model.fused_forward_backward(x, eps=eps)
         n = B * 32 * (H // 2) ** 2
         dz6 = torch.empty(n, device="cuda")
