@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 # main stream + three side streams (+ the communication stream, + a process group's own): more than HIP's default of 4
 # hardware queues, and streams that share a queue serialise (measured with a process group present: 1.47 ms/step at 4
 # queues, 1.39 at 6..8; without one 4..8 are the same).  Set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6" if os.environ.get("VAE_DP_OVERLAP") == "1" else "8")   # (see torch_vae_amd/__init__.py)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -99,7 +99,8 @@ def extra_records(args, dev, model, batches, Namespace, VanillaVAE, SyntheticPia
       elbo_rel_gap  the benched storage mode against the parity-proven f32 mode on the same weights, batch and noise
       f32           the same workload in the f32 kernel mode (the configuration that meets the 1e-4 ELBO target)
       reference_exact_32x32   SURVEY.md 8(d) config 2 at the reference's own 32x32 model
-      train_one_epoch_samples_per_s   the drop-in loop itself: host batches, H2D copy and the per-step loss read-back"""
+      train_one_epoch_samples_per_s   the drop-in loop itself over host-resident uint8 batches (prefetched H2D copy, expansion on the
+                                      device, the loop's loss bookkeeping); train_one_epoch_f32_host_samples_per_s: float32 host batches"""
     H, L, B = args.size, args.latent, args.batch
     gen = H != 32
     out = {}
@@ -151,6 +152,16 @@ def extra_records(args, dev, model, batches, Namespace, VanillaVAE, SyntheticPia
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader, device=dev, epoch=2)
+    torch.cuda.synchronize()
+    out["train_one_epoch_f32_host_samples_per_s"] = round(nb * B / (time.perf_counter() - t0), 1)
+    # the same loop fed uint8 pianorolls (the cells are 0/1: INTEGRATION.md shows the one-line collate change): copied one batch
+    # ahead on a copy stream, expanded to float32 on the device
+    host8 = [(h[0].to(torch.uint8).pin_memory(), h[1]) for h in host]
+    loader8 = [host8[i % 4] for i in range(nb)]
+    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8[:4], device=dev, epoch=2)     # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8, device=dev, epoch=2)
     torch.cuda.synchronize()
     out["train_one_epoch_samples_per_s"] = round(nb * B / (time.perf_counter() - t0), 1)
     return out

@@ -235,3 +235,24 @@ def test_checkpoint_helpers_format_and_atomicity(tmp_path):
     assert utils.should_save(cfg) is True and utils.should_save(cfg, fix_rank_gate=True) is False
     cfg.model_output_dir = None
     assert utils.should_save(cfg) is False
+
+
+def test_byte_loader_detection_and_overlap_refusal(monkeypatch):
+    """Host logic of the training loop that needs no GPU: which dataloaders take the uint8 path of train_one_epoch, and the loud
+    refusal of the overlapped gradient exchange when eight HIP hardware queues are configured (the 2.5x-slower combination)."""
+    from torch_vae_amd import train
+    f32 = [(torch.zeros(2, 1, 32, 32), torch.zeros(2, dtype=torch.long))]
+    u8 = [(torch.zeros(2, 1, 32, 32, dtype=torch.uint8), torch.zeros(2, dtype=torch.long))]
+    b1 = [(torch.zeros(2, 1, 32, 32, dtype=torch.bool), torch.zeros(2, dtype=torch.long))]
+    assert not train._is_byte_loader(f32) and train._is_byte_loader(u8) and train._is_byte_loader(b1) and not train._is_byte_loader([])
+
+    class Tagged:
+        byte_stimuli = True
+    assert train._is_byte_loader(Tagged()) and not train._is_byte_loader(iter(f32))
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES=8"):
+        train._refuse_overlap_on_eight_queues()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    train._refuse_overlap_on_eight_queues()
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    train._refuse_overlap_on_eight_queues()          # HIP's own default is four

@@ -400,6 +400,32 @@ def test_train_one_epoch_matches_reference_loop():
     assert torch.equal(model2.flat_parameters(), model.flat_parameters())
 
 
+def test_train_one_epoch_byte_stimuli_match_float_stimuli():
+    """The loop fed uint8 pianorolls (copied one batch ahead on a copy stream, expanded to float32 on the device) walks the same
+    trajectory, bit for bit, as the loop fed the float32 batches the reference's DataLoader hands over."""
+    from argparse import Namespace
+    from torch_vae_amd.train import build_optimizer, train_one_epoch
+    H, L, B, steps = 32, 16, 6, 5
+    cfg = Namespace(batch_size_per_gpu=B, world_size=1, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW", scheduler="OneCycle",
+                    epochs=1, log_wandb=False, print_interval=1000, log_interval=1000, freeze_encoder=False, global_rank=0)
+    xs = [torch.from_numpy(vo.synth_pianoroll(B, H, 40 + s)) for s in range(steps)]
+    assert all(bool(((x == 0) | (x == 1)).all()) for x in xs)
+    out = []
+    for as_bytes in (False, True):
+        torch.manual_seed(0)
+        model = make_model(H, L, False, "bf16", vo.init_params(L, H, 3, False), kld_weight=1.0)
+        opt, sched = build_optimizer(cfg, model, steps_per_epoch=steps)
+        epss = iter([torch.from_numpy(vo.counter_normal(B * L, 40 + s, 5).reshape(B, L)).float().cuda() for s in range(steps)])
+        orig = model.fused_train_step
+        model.fused_train_step = lambda o, x, _orig=orig, _it=epss, **k: _orig(o, x, **{**k, "eps": next(_it)})
+        loader = [((x.to(torch.uint8).pin_memory() if as_bytes else x), torch.zeros(B, dtype=torch.long)) for x in xs]
+        res, total_step, n_seen = train_one_epoch(cfg, model, opt, sched, model.loss, loader, device="cuda", epoch=2)
+        assert total_step == steps and n_seen == steps * B
+        out.append((res["loss"], model.flat_parameters().clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+
+
 def test_pipelined_and_simple_conv_kernels_agree():
     """The persistent/prefetched conv kernels (conv_pipe.cuh; wave-independent tiles and the 2x2 wave layout) against
     the one-tile-per-workgroup ones.  f32: exact arithmetic, only the summation order of the BatchNorm statistics
@@ -1070,11 +1096,22 @@ def test_library_allreduce_single_rank_rccl():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        queues = os.environ.get("GPU_MAX_HW_QUEUES")
         for mode in (False, True):
+            if mode:
+                # eight hardware queues (the package's default) + the overlapped exchange is the 2.5x-slower combination: refused
+                os.environ["GPU_MAX_HW_QUEUES"] = "8"
+                with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES"):
+                    one_step(mode)
+                os.environ["GPU_MAX_HW_QUEUES"] = "6"     # (the check reads the variable; HIP read it when it started: results do not depend on it)
             got = one_step(mode)
             for a, b in zip(got, ref):
                 np.testing.assert_array_equal(a, b)
     finally:
+        if queues is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = queues
         dist.destroy_process_group()
     # the entry points refuse to run without a communicator, loudly
     m = make_model(H, L, gen, "f32", p)

@@ -10,7 +10,10 @@ import os as _os
 # The step uses five HIP streams (caller's + three side streams + communication); HIP's default of four hardware
 # queues makes streams share queues and serialise (+10 % step time once RCCL's streams exist).  Read when HIP starts,
 # so it only takes effect if this package is imported before the first HIP call; harmless otherwise.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# With the bucketed gradient exchange (VAE_DP_OVERLAP=1: a sixth stream in flight) EIGHT queues are pathological on MI355X - 2.8 ms
+# per step against 1.1 (tools/diag/gpu_dp_exchange.py; independent of the communication stream's priority class) - and six are
+# not (1.18 ms), so that mode asks for six; train.fused_step refuses the overlapped exchange when eight are configured.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6" if _os.environ.get("VAE_DP_OVERLAP") == "1" else "8")
 
 from .types_helpers import EncoderOutput, LossOutput, ModelOutput  # noqa: F401,E402
 

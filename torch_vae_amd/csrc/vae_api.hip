@@ -66,7 +66,13 @@ static DevStreams* device_streams(int side_prio) {
     DevStreams* d = new DevStreams();
     bool ok = true;
     for (int i = 0; i < vae_ctx::NSIDE && ok; ++i) ok = hipStreamCreateWithPriority(&d->side[i], hipStreamNonBlocking, side_prio) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking) == hipSuccess;
+    {   // communication stream; VAE_COMM_STREAM_PRIO = high | low picks another priority class (diagnostics of the queue mapping)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* e = getenv("VAE_COMM_STREAM_PRIO");
+        if (e && (!strcmp(e, "high") || !strcmp(e, "low"))) ok = ok && hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, !strcmp(e, "high") ? hi : lo) == hipSuccess;
+        else ok = ok && hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking) == hipSuccess;
+    }
     if (!ok) { delete d; return nullptr; }
     pool[dev] = d;
     return d;
@@ -228,6 +234,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
     if (!strcmp(name, "use_fused_convout")) { c->use_fused_convout = value; return 0; }
     if (!strcmp(name, "use_convout_stream")) { c->use_convout_stream = value; return 0; }
+    if (!strcmp(name, "use_wgrad_split")) { c->use_wgrad_split = value; return 0; }
     if (!strcmp(name, "knob_convout_bands")) { c->knob_convout_bands = value; return 0; }
     if (!strcmp(name, "knob_convout_step_grid")) { c->knob_convout_step_grid = value > 0 ? value : 1; return 0; }
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }

@@ -9,6 +9,7 @@
 #include "conv_deep.cuh"
 #include "latent_mfma.cuh"
 #include "convout_stream.cuh"
+#include "wgrad_split.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -258,7 +259,20 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
     const bool convt = a.g_two != 0;
 #define WG_CASE(A_, B_, C_, P_) { if (set_lds(wgrad_kernel<T, A_, B_, C_, P_>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, A_, B_, C_, P_>), grid, dim3(256), lds, st, a); }
 #define WG_KIND(A_, B_, P_) { if (convt) WG_CASE(A_, B_, true, P_) else WG_CASE(A_, B_, false, P_) }
-    if (WA == 4) {
+    bool split_done = false;
+    if constexpr (sizeof(T) == 2) {
+        // producer / consumer form of the wide tile (wgrad_split.cuh): same results, staging and MFMA halves in different waves
+        const int npix = TB * (2 * th + 1) * (2 * tw + 1);
+        if (WA == 4 && pre && !raw && c->use_wgrad_split && c->use_tr16 && npix * (int)(32 * sizeof(T) / 16) <= wsp::MAXG * wsp::NP &&
+            wgrad_split_lds<T>(npix) <= 160 * 1024) {
+            const size_t lds2 = wgrad_split_lds<T>(npix);
+            if (convt) { if (set_lds(wgrad_split_kernel<T, true>, lds2)) return -1; hipLaunchKernelGGL((wgrad_split_kernel<T, true>), grid, dim3(1024), lds2, st, a); }
+            else { if (set_lds(wgrad_split_kernel<T, false>, lds2)) return -1; hipLaunchKernelGGL((wgrad_split_kernel<T, false>), grid, dim3(1024), lds2, st, a); }
+            split_done = true;
+        }
+    }
+    if (split_done) {}
+    else if (WA == 4) {
         if constexpr (sizeof(T) == 2) {
             if (raw) { if (set_lds(wgrad_kernel<T, 4, 1, false, true, 8, true>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, false, true, 8, true>), grid, dim3(512), lds, st, a); }
             else if (convt) { if (set_lds(wgrad_kernel<T, 4, 1, true, true, 8>, lds)) return -1; hipLaunchKernelGGL((wgrad_kernel<T, 4, 1, true, true, 8>), grid, dim3(512), lds, st, a); }

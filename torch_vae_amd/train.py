@@ -116,6 +116,20 @@ def allreduce_gradients(model: VanillaVAE, optimizer=None):
     return []
 
 
+def _refuse_overlap_on_eight_queues():
+    """The overlapped (bucketed) gradient exchange with eight or more HIP hardware queues runs the whole step 2.5x slower on MI355X
+    (2.8 ms against 1.1 ms; 1.18 ms with six queues - tools/diag/gpu_dp_exchange.py): refuse it loudly instead
+    of training at that speed.  The queue count is read by HIP when it starts, so it cannot be corrected from here."""
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    if queues >= 8:
+        raise RuntimeError(f"overlapped gradient exchange (overlap=True / VAE_DP_OVERLAP=1) with GPU_MAX_HW_QUEUES={queues}: this "
+                           "combination is 2.5x slower than the in-line exchange on MI355X; export GPU_MAX_HW_QUEUES=6 (or "
+                           "VAE_DP_OVERLAP=1, which selects 6) before the process starts, or use the default in-line exchange")
+
+
 def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool = True, overlap: bool | None = None):
     """One training step on the fused path (train.py:634-656): forward, ELBO, backward, [gradient all-reduce], AdamW.
     Data parallel (the product path on a multi-GPU node): by default both gradient buckets go out as ONE RCCL group
@@ -123,8 +137,8 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     (3 MB of f32 gradients: measured +15 us per step with a one-rank communicator on MI355X).  ``overlap=True`` puts the
     decoder bucket's all-reduce on the context's communication stream between the two halves of the backward, under
     the encoder half, the encoder bucket following in line; measured here that costs more than the ~40 us it can hide
-    (+40..+70 us: a second host call into the backward, two event hand-offs; +0.6 ms in one configuration of hardware
-    queues), so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
+    (+70 us with six hardware queues: event hand-offs and a sixth stream; with eight queues the whole step runs 2.5x
+    slower, which this function refuses), so it is opt-in: ``overlap=True`` or VAE_DP_OVERLAP=1."""
     one_call = isinstance(optimizer, FusedAdamW) and os.environ.get("VAE_ONE_CALL_STEP", "1") != "0"
     if one_call:
         optimizer._bind()
@@ -136,6 +150,8 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     else:
         if overlap is None:
             overlap = os.environ.get("VAE_DP_OVERLAP", "0") == "1"
+        if overlap:
+            _refuse_overlap_on_eight_queues()
         if one_call:
             model._context(x.shape[0])   # (creates the context - and with it the library's communicator - on the first step)
         if one_call and model.library_comm_world() == _dp_world():
@@ -152,9 +168,60 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     return out3, xhat
 
 
+class _ByteBatchPrefetcher:
+    """Iterates a dataloader whose stimuli are uint8 / bool pianorolls (0/1 cells: a quarter of the float32 bytes) one batch
+    ahead: the next batch's host-to-device copy runs on a copy stream beside the current step, and the expansion to float32
+    is one elementwise kernel on the compute stream.  A 4 MB copy hides under a 1.1 ms step where the 16.8 MB float32 copy
+    did not (train_one_epoch's note on blocking copies)."""
+
+    def __init__(self, dataloader, device):
+        self.it, self.device = iter(dataloader), torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._next = None
+        self._fetch()
+
+    def _fetch(self):
+        try:
+            stimuli, y_true = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        with torch.cuda.stream(self.stream):
+            dev = stimuli.to(self.device, non_blocking=True)
+            yd = y_true.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._next = (dev, yd, ev)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        dev, yd, ev = self._next
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        dev.record_stream(cur); yd.record_stream(cur)
+        x = dev.to(torch.float32)          # the kernels read float32 stimuli (0.0 / 1.0 exactly)
+        self._fetch()
+        return x, yd
+
+
+def _is_byte_loader(dataloader):
+    """True for list / tuple loaders of (uint8 | bool stimuli, labels) and for loaders that say so (``byte_stimuli = True``)."""
+    if getattr(dataloader, "byte_stimuli", False):
+        return True
+    if isinstance(dataloader, (list, tuple)) and dataloader:
+        first = dataloader[0][0]
+        return torch.is_tensor(first) and first.dtype in (torch.uint8, torch.bool)
+    return False
+
+
 def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, device="cuda", epoch=1, n_epoch=None,
                     total_step=0, n_samples_seen=0, verbose=False):
-    """Train the model for one epoch (train.py:554-767)."""
+    """Train the model for one epoch (train.py:554-767).  Stimuli may also arrive as uint8 / bool pianorolls (a list of batches,
+    or a loader with ``byte_stimuli = True``): they are copied one batch ahead on a copy stream and expanded on the device."""
     model.train()
     log_wandb = bool(getattr(config, "log_wandb", False))
     if log_wandb:
@@ -165,13 +232,17 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
     world = _dp_world()
     fused = (isinstance(model, VanillaVAE) and isinstance(optimizer, FusedAdamW)
              and getattr(criterion, "__self__", None) is model and not getattr(config, "freeze_encoder", False))
-    for batch_idx, (stimuli, y_true) in enumerate(dataloader):
+    n_batches = len(dataloader)
+    batches = _ByteBatchPrefetcher(dataloader, device) if (_is_byte_loader(dataloader) and torch.device(device).type == "cuda") else dataloader
+    for batch_idx, (stimuli, y_true) in enumerate(batches):
         batch_size_this_gpu = stimuli.shape[0]
         # (blocking copies, as train.py:630-631: measured on MI355X, asynchronous copies of the pinned 16.8 MB batch are SLOWER
         #  here - 1.80 ms/step on the compute stream, 3.0 ms/step prefetched on a copy stream beside the step - than the
         #  blocking copy's 1.66 ms/step)
         stimuli = stimuli.to(device)
         y_true = y_true.to(device)
+        if stimuli.dtype != torch.float32:
+            stimuli = stimuli.to(torch.float32)
         if fused:
             # train.py:634-656 as one HIP chain: forward, ELBO, backward, [all-reduce], AdamW
             out3, reconstruction = fused_step(model, optimizer, stimuli, use_device_eps=False)
@@ -195,7 +266,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
         # per step.  Here they stay on the device unless this step prints or logs them: the epoch sum is accumulated on the
         # device in float64, in step order - bit for bit the Python sum of the per-step float32 values.
         rank0 = getattr(config, "global_rank", 0) == 0
-        printing = batch_idx <= 2 or batch_idx % config.print_interval == 0 or batch_idx >= len(dataloader) - 1
+        printing = batch_idx <= 2 or batch_idx % config.print_interval == 0 or batch_idx >= n_batches - 1
         logging = log_wandb and rank0 and batch_idx % config.log_interval == 0
         first_verbose = epoch <= 1 and batch_idx == 0 and verbose
         if loss_epoch_dev is None:
@@ -211,7 +282,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
             if rank0:
                 print(
                     f"Train Epoch:{epoch:4d}" + (f"/{n_epoch}" if n_epoch is not None else ""),
-                    f" Step:{batch_idx + 1:4d}/{len(dataloader)}",
+                    f" Step:{batch_idx + 1:4d}/{n_batches}",
                     f" Loss:[F: {loss_batch:6.3f}, KL: {loss_kld:6.3f}]",
                     f" LR: {scheduler.get_last_lr()[0]:.5f}",
                     f" KL Weight: {model.kld_weight:.5f}",
@@ -219,7 +290,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
         if logging:
             wandb.log({
                 "training/stepwise/epoch": epoch,
-                "training/stepwise/epoch_progress": epoch - 1 + (batch_idx + 1) / len(dataloader),
+                "training/stepwise/epoch_progress": epoch - 1 + (batch_idx + 1) / n_batches,
                 "training/stepwise/n_samples_seen": n_samples_seen,
                 "training/stepwise/train/loss": loss_batch,
                 "training/stepwise/train/loss_recon": loss_recon,
@@ -227,7 +298,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
                 "training/stepwise/train/kld_weight": model.kld_weight,
             }, step=total_step)
     loss_epoch = float(loss_epoch_dev) if loss_epoch_dev is not None else 0.0   # the epoch's one unconditional synchronisation
-    results = {"loss": loss_epoch / len(dataloader)}
+    results = {"loss": loss_epoch / n_batches}
     return results, total_step, n_samples_seen
 
 
