@@ -1121,6 +1121,39 @@ def test_library_allreduce_single_rank_rccl():
     assert b"no communicator" in _lib.lib().vae_last_error()
 
 
+@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 9)])
+def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
+    """final_layer.0's forward on 128x128 images runs as a row-streaming kernel (upfinal_stream.cuh: LDS-DMA ring, transposed MFMAs,
+    bands of rows per workgroup).  Same products and the same rounding points as the tiled kernel (up2_kernel); the f32 accumulation
+    visits the taps in another order and adds the bias last, so a few stored values per 10^5 round the other way (measured
+    0.003-0.04 %, always by one storage ulp) and everything downstream follows at that level."""
+    from torch_vae_amd import _lib
+    H, L = 128, 16
+    p = perturbed_params(L, H, 21, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 8)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 8, 5).reshape(B, L)).float().cuda()
+    res = []
+    for stream in (0, 1):
+        m = make_model(H, L, True, dtype, p, kld_weight=1.0)
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_upf_stream", stream), "set")
+        out3, xhat = m.fused_forward_backward(x, eps=eps)
+        n = B * 32 * H * H
+        y7 = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 7, y7.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        torch.cuda.synchronize()
+        res.append((out3.cpu().numpy(), xhat.cpu().numpy(), y7.cpu().numpy(), m.flat_grads().cpu().numpy(), m._bnflat.cpu().numpy()))
+    (o0, x0, y0, g0, b0), (o1, x1, y1, g1, b1) = res
+    frac = float((y0 != y1).mean())
+    ulp = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}[dtype]
+    worst = float((np.abs(y0 - y1) / np.maximum(np.abs(y0), 1e-30)).max())
+    report(test="streaming_final_convt", dtype=dtype, batch=B, differing_fraction=frac, worst_rel=worst, grads=rel_l2(g1, g0))
+    assert frac < 2e-3 and worst <= 1.01 * ulp, (frac, worst)
+    np.testing.assert_allclose(o1, o0, rtol=2e-5)
+    assert float(np.abs(x1 - x0).max()) < {"bf16": 5e-3, "f16": 1e-3}[dtype]
+    assert rel_l2(b1, b0) < 1e-6
+    assert rel_l2(g1, g0) < {"bf16": 5e-3, "f16": 1e-3}[dtype], rel_l2(g1, g0)
+
+
 @pytest.mark.parametrize("cfg", [(64, 16, 5, "bf16"), (128, 16, 3, "f16"), (32, 16, 9, "bf16"), (64, 64, 2, "f16")])
 def test_fused_dgrad_wgrad_matches_separate_kernels(cfg):
     """conv_fused.cuh (one pass over (dz, y) for the input AND the weight gradient of final_layer.0 / decoder.2) against the

@@ -10,6 +10,7 @@
 #include "latent_mfma.cuh"
 #include "convout_stream.cuh"
 #include "wgrad_split.cuh"
+#include "upfinal_stream.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -102,6 +103,27 @@ static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
 
 template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        // final_layer.0's forward on 128x128 images: the row-streaming kernel (upfinal_stream.cuh)
+        if (c->use_upf_stream && a.epi == EPI_FWD && a.Cin == 32 && a.Cout == 32 && a.Hs == ufs::HL && a.Ws == ufs::WL && !a.stage_out && !a.two_src) {
+            UpFinalStreamArgs<T> m;
+            m.yin = a.src0; m.coef = a.coef; m.slope = a.slope; m.fuse = a.fuse; m.wp = a.wp; m.bias = a.bias; m.out = a.out; m.stat = a.stat; m.B = a.B;
+            const int ncu = 256;
+            long best = -1; int nb = 1;
+            for (int cand = 1; cand <= 8 && ufs::HL / cand >= 8; cand *= 2) {
+                const long rounds = ((long)a.B * cand + ncu - 1) / ncu, cost = rounds * (ufs::HL / cand / 4 + 2);
+                if (best < 0 || cost < best) { best = cost; nb = cand; }
+            }
+            m.nb = nb; m.RB = ufs::HL / nb; m.n_units = a.B * nb;
+            const double px_in = (double)a.B * a.Hs * a.Ws;
+            ProfScope ps(c, "up_fwd(convT)", sizeof(T) * (px_in * 32 + 4 * px_in * 32 + 9.0 * 32 * 32), 2.0 * 9 * 32 * 32 * px_in, st);
+            const size_t lds = upfinal_stream_lds();
+            if (set_lds(upfinal_stream_kernel<T>, lds)) return -1;
+            hipLaunchKernelGGL((upfinal_stream_kernel<T>), dim3(std::min(m.n_units, ncu)), dim3(1024), lds, st, m);
+            LAUNCH_CHECK("upfinal_stream_kernel");
+            return 0;
+        }
+    }
     if (c->use_pipelined) { const int rc = launch_conv_deep<T>(c, a, false, st); if (rc <= 0) return rc; }
     if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, false, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
