@@ -1145,9 +1145,11 @@ def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
     (o0, x0, y0, g0, b0), (o1, x1, y1, g1, b1) = res
     frac = float((y0 != y1).mean())
     ulp = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}[dtype]
-    worst = float((np.abs(y0 - y1) / np.maximum(np.abs(y0), 1e-30)).max())
-    report(test="streaming_final_convt", dtype=dtype, batch=B, differing_fraction=frac, worst_rel=worst, grads=rel_l2(g1, g0))
-    assert frac < 2e-3 and worst <= 1.01 * ulp, (frac, worst)
+    # one storage rounding step where the value is of normal size; where the taps cancel (|y| tiny against its terms) the two
+    # summation orders differ by f32 rounding of the terms instead: 1e-6 of the tensor's largest magnitude bounds that
+    excess = float((np.abs(y0 - y1) - 1.01 * ulp * np.abs(y0)).max() / np.abs(y0).max())
+    report(test="streaming_final_convt", dtype=dtype, batch=B, differing_fraction=frac, excess_over_one_ulp=excess, grads=rel_l2(g1, g0))
+    assert frac < 2e-3 and excess <= 1e-6, (frac, excess)   # (measured 1e-8 .. 2.5e-8)
     np.testing.assert_allclose(o1, o0, rtol=2e-5)
     assert float(np.abs(x1 - x0).max()) < {"bf16": 5e-3, "f16": 1e-3}[dtype]
     assert rel_l2(b1, b0) < 1e-6
