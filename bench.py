@@ -158,7 +158,7 @@ def extra_records(args, dev, model, batches, Namespace, VanillaVAE, SyntheticPia
     # ahead on a copy stream, expanded to float32 on the device
     host8 = [(h[0].to(torch.uint8).pin_memory(), h[1]) for h in host]
     loader8 = [host8[i % 4] for i in range(nb)]
-    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8[:4], device=dev, epoch=2)     # warm-up
+    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8[:min(nb, 12)], device=dev, epoch=2)     # warm-up (the copy stream's allocator blocks, the pinned staging: the first epoch over a new loader is 10 % slower)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8, device=dev, epoch=2)
