@@ -354,6 +354,7 @@ template <typename T> struct WgradArgs {
     int use_tr16, rev;
     unsigned m_pp, m_pw, m_tx, m_txy;
     BnFuse fuse;                                                 // mode == BNF_BWD: the gradient operand's coefficients come from batch statistics
+    long long* dbg;                                              // diagnostic builds only (wgrad_split_kernel): per-wave cycle counters
 };
 
 

@@ -287,6 +287,7 @@ static int launch_wgrad(vae_ctx* c, WgradArgs<T> a, float* dw_out, hipStream_t s
         const int npix = TB * (2 * th + 1) * (2 * tw + 1);
         if (WA == 4 && pre && !raw && c->use_wgrad_split && c->use_tr16 && npix * (int)(32 * sizeof(T) / 16) <= wsp::MAXG * wsp::NP &&
             wgrad_split_lds<T>(npix) <= 160 * 1024) {
+            a.dbg = (c->dbg_buf && c->tag && !strcmp(c->tag, c->dbg_tag) && c->dbg_epi == 32) ? c->dbg_buf : nullptr;   // (vae_debug_stamps(tag, 32, buf))
             const size_t lds2 = wgrad_split_lds<T>(npix);
             if (convt) { if (set_lds(wgrad_split_kernel<T, true>, lds2)) return -1; hipLaunchKernelGGL((wgrad_split_kernel<T, true>), grid, dim3(1024), lds2, st, a); }
             else { if (set_lds(wgrad_split_kernel<T, false>, lds2)) return -1; hipLaunchKernelGGL((wgrad_split_kernel<T, false>), grid, dim3(1024), lds2, st, a); }

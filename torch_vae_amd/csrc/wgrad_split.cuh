@@ -77,7 +77,14 @@ __global__ __launch_bounds__(1024) void wgrad_split_kernel(WgradArgs<T> a) {
         const int bt = fastdiv(tile, a.m_txy), trem = tile - bt * a.tiles_x * a.tiles_y, ty = fastdiv(trem, a.m_tx), tx = trem - ty * a.tiles_x;
         b0 = bt << a.lTB; y0 = ty << a.lth; x0 = tx << a.ltw;
     };
+#ifdef VAE_PHASE_STAMPS
+    long long dst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long dst_entry_ = clock64(); long long dst_t_ = dst_entry_;
+#define WSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const long long t1_ = clock64(); dst_[k] += t1_ - dst_t_; dst_t_ = t1_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WSTAMP(k)
+#endif
     deep::barrier_lds();                   // coefficient rows / table published
+    WSTAMP(0)
 
     if (wave >= 8) {
         // =========================== producers ===========================
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(1024) void wgrad_split_kernel(WgradArgs<T> a) {
                     ps0[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s0) + g);
                     if constexpr (S_TWO) ps1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.s1) + g);
                 }
+                WSTAMP(3)
                 int2 e[MAXG];
 #pragma unroll
                 for (int u = 0; u < MAXG; ++u) e[u] = gtab[pt + u * NP];
@@ -185,7 +193,9 @@ __global__ __launch_bounds__(1024) void wgrad_split_kernel(WgradArgs<T> a) {
                     if constexpr (G_TWO) pg1[u] = *reinterpret_cast<const Vec16<T>*>(reinterpret_cast<const char*>(a.g1) + g);
                 }
             }
+            WSTAMP(1)
             deep::barrier_lds();             // tile i published / tile i-1 consumed (raw: the next tile's global loads stay in flight)
+            WSTAMP(2)
         }
     } else {
         // =========================== consumers ===========================
@@ -220,7 +230,9 @@ __global__ __launch_bounds__(1024) void wgrad_split_kernel(WgradArgs<T> a) {
                     }
                 }
             }
+            WSTAMP(1)
             deep::barrier_lds();
+            WSTAMP(2)
         }
         // partial slab: rows = low-res-side channel (a), lanes = high-res-side channel (b)
         const size_t slab_id = blockIdx.x;
@@ -236,4 +248,8 @@ __global__ __launch_bounds__(1024) void wgrad_split_kernel(WgradArgs<T> a) {
             }
         }
     }
+#ifdef VAE_PHASE_STAMPS
+    if (a.dbg && lane == 0) { dst_[5] = clock64() - dst_entry_; for (int k_ = 0; k_ < 8; ++k_) a.dbg[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + wave) * 8 + k_] = dst_[k_]; }
+#endif
+#undef WSTAMP
 }
