@@ -290,6 +290,9 @@ def sigmoid(v):
 # --------------------------------------------------------------------------
 # storage emulation (16-bit kernel modes)
 # --------------------------------------------------------------------------
+F16_FLUSH_SUBNORMALS = False
+
+
 def round_storage(a: np.ndarray, storage: str | None, scale: float = 1.0) -> np.ndarray:
     """Round to the grid of the HIP path's 16-bit storage type ("bf16" / "f16"; None: identity), round-to-nearest-even, keeping
     the array's dtype.  `scale` (a power of two): the f16 mode stores its gradients multiplied by it (torch_vae_amd/csrc/vae_ctx.h:
@@ -300,6 +303,8 @@ def round_storage(a: np.ndarray, storage: str | None, scale: float = 1.0) -> np.
     if storage == "f16":
         with np.errstate(over="ignore"):
             r = v.astype(np.float16).astype(a.dtype)
+        if F16_FLUSH_SUBNORMALS:          # (experiment switch, tools/diag/gpu_emu_gaps.py: results below 2^-14 become zero)
+            r = np.where(np.abs(r) < 2.0 ** -14, r * 0, r)
     elif storage == "bf16":
         f = np.ascontiguousarray(v, dtype=np.float32)
         u = f.view(np.uint32)

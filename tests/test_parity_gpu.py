@@ -1121,7 +1121,7 @@ def test_library_allreduce_single_rank_rccl():
     assert b"no communicator" in _lib.lib().vae_last_error()
 
 
-@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 9)])
+@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 9), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
 def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
     """final_layer.0's forward on 128x128 images runs as a row-streaming kernel (upfinal_stream.cuh: LDS-DMA ring, transposed MFMAs,
     bands of rows per workgroup).  Same products and the same rounding points as the tiled kernel (up2_kernel); the f32 accumulation
@@ -1278,7 +1278,7 @@ def test_deferred_output_conv_matches_separate_kernels(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("B,bands", [(3, 0), (2, 1), (5, 4), (2, 16)])
+@pytest.mark.parametrize("B,bands", [(3, 0), (2, 1), (5, 4), (2, 16), (20, 16)])   # (20 x 16 bands = 320 units: workgroups walk more than one)
 def test_streaming_output_conv_matches_tiled_kernel(dtype, B, bands):
     """128-pixel-wide images take the row-streaming form of the fused output-conv kernel (convout_stream.cuh: LDS rings filled by
     LDS-DMA, transposed MFMAs, whole rows or bands of rows per workgroup).  Same arithmetic element for element as the tiled kernel

@@ -13,6 +13,7 @@ m = make_model(H, L, gen, dtype, p)
 m.fused_forward_backward(torch.from_numpy(x).cuda(), eps=torch.from_numpy(eps).float().cuda())
 got = flat_grad_dict(m)
 c = vo.forward(p, x.astype(np.float64), eps, None, train=True); g = vo.backward(p, c)
+vo.F16_FLUSH_SUBNORMALS = os.environ.get("EMU_F16_FLUSH") == "1"
 ce = vo.forward(p, x.astype(np.float64), eps, None, train=True, storage=dtype); ge = vo.backward(p, ce)
 for n in got:
     if n in PRE_BN_BIAS: continue
