@@ -39,8 +39,9 @@ FWD_TOL = {"f32": 1e-4, "bf16": 2e-2, "f16": 3e-3}        # xhat rel-L2
 # Measured on MI355X over the 20 adversarial small cases x 31 tensors (gpurun_out/parity_report.jsonl, test "every_tensor_vs_emulated_storage"):
 # bf16: the worst tensor of a case sits at 0.004-0.06 (median 0.009; three cases at 0.06-0.093), where the same steps measure 0.11-0.21 against the
 # exact oracle; whole cases agree to 0.000-0.005 on every tensor (tools/diag/gpu_emu_gaps.py).  f16: 0.02-0.07 (median 0.03) against 0.03-0.10.
-# What is left in the outliers is a handful of LeakyReLU slope decisions on pre-activations within one f32 rounding step of zero (the kernels'
-# BatchNorm sums are f32 partials added in f64, the oracle's are exact), each of which moves the small tensors downstream by a few per cent.
+# What is left was traced (tools/diag/gpu_emu_dz.py): f32-in-MFMA-order vs f64 accumulation makes a growing share of the stored values differ
+# by one ulp (26 % of y7 at final_layer), and the ~0.04 % of elements whose pre-activation lies within one storage ulp of zero then take the
+# other LeakyReLU slope: they carry 99 % of dz7's 2.8 % mismatch, which travels down the decoder.  Not reproducible by any CPU emulation.
 EMU_GRAD_TOL = {"bf16": 0.12, "f16": 0.09}
 EMU_ELBO_TOL = {"bf16": 2e-3, "f16": 5e-4}
 
