@@ -99,8 +99,8 @@ def extra_records(args, dev, model, batches, Namespace, VanillaVAE, SyntheticPia
       elbo_rel_gap  the benched storage mode against the parity-proven f32 mode on the same weights, batch and noise
       f32           the same workload in the f32 kernel mode (the configuration that meets the 1e-4 ELBO target)
       reference_exact_32x32   SURVEY.md 8(d) config 2 at the reference's own 32x32 model
-      train_one_epoch_samples_per_s   the drop-in loop itself over host-resident uint8 batches (prefetched H2D copy, expansion on the
-                                      device, the loop's loss bookkeeping); train_one_epoch_f32_host_samples_per_s: float32 host batches"""
+      train_one_epoch_samples_per_s   the drop-in loop itself over host-resident BIT-PLANE batches (0.5 MB copy, expansion on the device,
+                                      the loop's loss bookkeeping); train_one_epoch_{uint8,f32}_host_samples_per_s: byte / float32 host batches"""
     H, L, B = args.size, args.latent, args.batch
     gen = H != 32
     out = {}
@@ -154,14 +154,24 @@ def extra_records(args, dev, model, batches, Namespace, VanillaVAE, SyntheticPia
     train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader, device=dev, epoch=2)
     torch.cuda.synchronize()
     out["train_one_epoch_f32_host_samples_per_s"] = round(nb * B / (time.perf_counter() - t0), 1)
-    # the same loop fed uint8 pianorolls (the cells are 0/1: INTEGRATION.md shows the one-line collate change): copied one batch
-    # ahead on a copy stream, expanded to float32 on the device
+    # the same loop fed uint8 pianorolls (the cells are 0/1: INTEGRATION.md shows the one-line collate change): 4 MB blocking copy,
+    # expanded to float32 on the device
     host8 = [(h[0].to(torch.uint8).pin_memory(), h[1]) for h in host]
     loader8 = [host8[i % 4] for i in range(nb)]
     train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8[:min(nb, 12)], device=dev, epoch=2)     # warm-up (the copy stream's allocator blocks, the pinned staging: the first epoch over a new loader is 10 % slower)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     train_one_epoch(cfgl, ml, ol, sl, ml.loss, loader8, device=dev, epoch=2)
+    torch.cuda.synchronize()
+    out["train_one_epoch_uint8_host_samples_per_s"] = round(nb * B / (time.perf_counter() - t0), 1)
+    # ... and bit planes (torch_vae_amd.train.pack_bits: 0.5 MB per batch), expanded on the device
+    from torch_vae_amd.train import pack_bits
+    hostb = [(pack_bits(h[0]).pin_memory(), h[1]) for h in host]
+    loaderb = [hostb[i % 4] for i in range(nb)]
+    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loaderb[:min(nb, 12)], device=dev, epoch=2)     # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    train_one_epoch(cfgl, ml, ol, sl, ml.loss, loaderb, device=dev, epoch=2)
     torch.cuda.synchronize()
     out["train_one_epoch_samples_per_s"] = round(nb * B / (time.perf_counter() - t0), 1)
     return out

@@ -237,18 +237,21 @@ def test_checkpoint_helpers_format_and_atomicity(tmp_path):
     assert utils.should_save(cfg) is False
 
 
-def test_byte_loader_detection_and_overlap_refusal(monkeypatch):
-    """Host logic of the training loop that needs no GPU: which dataloaders take the uint8 path of train_one_epoch, and the loud
-    refusal of the overlapped gradient exchange when eight HIP hardware queues are configured (the 2.5x-slower combination)."""
+def test_bit_plane_stimuli_and_overlap_refusal(monkeypatch):
+    """Host logic of the training loop that needs no GPU: bit-plane packing / expansion of 0/1 pianorolls (pack_bits and the loop's
+    expansion are inverse, in numpy.packbits order), and the loud refusal of the overlapped gradient exchange when eight HIP
+    hardware queues are configured (the 2.5x-slower combination)."""
     from torch_vae_amd import train
-    f32 = [(torch.zeros(2, 1, 32, 32), torch.zeros(2, dtype=torch.long))]
-    u8 = [(torch.zeros(2, 1, 32, 32, dtype=torch.uint8), torch.zeros(2, dtype=torch.long))]
-    b1 = [(torch.zeros(2, 1, 32, 32, dtype=torch.bool), torch.zeros(2, dtype=torch.long))]
-    assert not train._is_byte_loader(f32) and train._is_byte_loader(u8) and train._is_byte_loader(b1) and not train._is_byte_loader([])
-
-    class Tagged:
-        byte_stimuli = True
-    assert train._is_byte_loader(Tagged()) and not train._is_byte_loader(iter(f32))
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(3, 1, 16, 32, generator=g) < 0.3).float()
+    packed = train.pack_bits(x)
+    assert packed.dtype == torch.uint8 and packed.shape == (3, 1, 16, 4)
+    np.testing.assert_array_equal(packed.numpy(), np.packbits(x.numpy().astype(np.uint8), axis=-1))
+    assert torch.equal(train._expand_stimuli(packed, 32), x)
+    assert torch.equal(train._expand_stimuli(x.to(torch.uint8), 32), x) and torch.equal(train._expand_stimuli(x.bool(), 32), x)
+    assert train._expand_stimuli(x, 32) is x
+    with pytest.raises(ValueError):
+        train.pack_bits(torch.zeros(1, 1, 4, 12))
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES=8"):
         train._refuse_overlap_on_eight_queues()

@@ -402,8 +402,8 @@ def test_train_one_epoch_matches_reference_loop():
 
 
 def test_train_one_epoch_byte_stimuli_match_float_stimuli():
-    """The loop fed uint8 pianorolls (copied one batch ahead on a copy stream, expanded to float32 on the device) walks the same
-    trajectory, bit for bit, as the loop fed the float32 batches the reference's DataLoader hands over."""
+    """The loop fed uint8 pianorolls or bit planes (train.pack_bits; expanded to float32 on the device) walks the same trajectory,
+    bit for bit, as the loop fed the float32 batches the reference's DataLoader hands over."""
     from argparse import Namespace
     from torch_vae_amd.train import build_optimizer, train_one_epoch
     H, L, B, steps = 32, 16, 6, 5
@@ -412,19 +412,22 @@ def test_train_one_epoch_byte_stimuli_match_float_stimuli():
     xs = [torch.from_numpy(vo.synth_pianoroll(B, H, 40 + s)) for s in range(steps)]
     assert all(bool(((x == 0) | (x == 1)).all()) for x in xs)
     out = []
-    for as_bytes in (False, True):
+    from torch_vae_amd.train import pack_bits
+    for as_bytes in (False, True, "bits"):
         torch.manual_seed(0)
         model = make_model(H, L, False, "bf16", vo.init_params(L, H, 3, False), kld_weight=1.0)
         opt, sched = build_optimizer(cfg, model, steps_per_epoch=steps)
         epss = iter([torch.from_numpy(vo.counter_normal(B * L, 40 + s, 5).reshape(B, L)).float().cuda() for s in range(steps)])
         orig = model.fused_train_step
         model.fused_train_step = lambda o, x, _orig=orig, _it=epss, **k: _orig(o, x, **{**k, "eps": next(_it)})
-        loader = [((x.to(torch.uint8).pin_memory() if as_bytes else x), torch.zeros(B, dtype=torch.long)) for x in xs]
+        conv = {False: lambda t: t, True: lambda t: t.to(torch.uint8).pin_memory(), "bits": lambda t: pack_bits(t).pin_memory()}[as_bytes]
+        loader = [(conv(x), torch.zeros(B, dtype=torch.long)) for x in xs]
         res, total_step, n_seen = train_one_epoch(cfg, model, opt, sched, model.loss, loader, device="cuda", epoch=2)
         assert total_step == steps and n_seen == steps * B
         out.append((res["loss"], model.flat_parameters().clone()))
-    assert out[0][0] == out[1][0]
-    assert torch.equal(out[0][1], out[1][1])
+    for o in out[1:]:
+        assert out[0][0] == o[0]
+        assert torch.equal(out[0][1], o[1])
 
 
 def test_pipelined_and_simple_conv_kernels_agree():

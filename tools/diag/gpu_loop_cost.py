@@ -1,11 +1,11 @@
-"""Diagnostic (GPU box): where the drop-in loop's time goes.  Per-step time of train_one_epoch fed (a) float32 host batches, (b) uint8
-host batches through the prefetcher, (c) device-resident float32 batches, against the bare fused step."""
+"""Diagnostic (GPU box): where the drop-in loop's time goes.  Per-step time of train_one_epoch fed float32 host batches, uint8 host
+batches, bit-plane host batches (train.pack_bits) and device-resident float32 batches, against the bare fused step."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from argparse import Namespace
 from torch_vae_amd.models import VanillaVAE
-from torch_vae_amd.train import SyntheticPianorollLoader, build_optimizer, fused_step, train_one_epoch
+from torch_vae_amd.train import SyntheticPianorollLoader, build_optimizer, fused_step, train_one_epoch, pack_bits
 H, L, B, nb = 128, 16, 256, 40
 cfg = Namespace(batch_size_per_gpu=B, world_size=1, lr_relative=0.01, weight_decay=0.0, optimizer="AdamW", scheduler="OneCycle", epochs=1,
                 log_wandb=False, print_interval=100000, log_interval=100000, freeze_encoder=False, global_rank=0)
@@ -15,6 +15,7 @@ dev = [SyntheticPianorollLoader(B, H, 1, seed=i, device="cuda").batch(0)[0] for 
 lab = torch.zeros(B, dtype=torch.long)
 host32 = [(d.cpu().pin_memory(), lab) for d in dev]
 host8 = [(d.cpu().to(torch.uint8).pin_memory(), lab) for d in dev]
+hostb = [(pack_bits(d.cpu()).pin_memory(), lab) for d in dev]
 devl = [(d, lab.cuda()) for d in dev]
 def run(tag, loader):
     import io, contextlib
@@ -31,5 +32,6 @@ for i in range(nb): fused_step(model, opt, dev[i % 4]); sched.step()
 torch.cuda.synchronize(); print(f"bare fused_step + scheduler: {1e3 * (time.perf_counter() - t0) / nb:.3f} ms/step", flush=True)
 for rep in range(2):
     run("train_one_epoch, device-resident float32 batches", devl)
-    run("train_one_epoch, uint8 host batches (prefetched)", host8)
+    run("train_one_epoch, bit-plane host batches", hostb)
+    run("train_one_epoch, uint8 host batches", host8)
     run("train_one_epoch, float32 host batches (blocking copy)", host32)

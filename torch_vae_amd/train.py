@@ -168,60 +168,34 @@ def fused_step(model: VanillaVAE, optimizer, x, eps=None, use_device_eps: bool =
     return out3, xhat
 
 
-class _ByteBatchPrefetcher:
-    """Iterates a dataloader whose stimuli are uint8 / bool pianorolls (0/1 cells: a quarter of the float32 bytes) one batch
-    ahead: the next batch's host-to-device copy runs on a copy stream beside the current step, and the expansion to float32
-    is one elementwise kernel on the compute stream.  A 4 MB copy hides under a 1.1 ms step where the 16.8 MB float32 copy
-    did not (train_one_epoch's note on blocking copies)."""
-
-    def __init__(self, dataloader, device):
-        self.it, self.device = iter(dataloader), torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
-        self._next = None
-        self._fetch()
-
-    def _fetch(self):
-        try:
-            stimuli, y_true = next(self.it)
-        except StopIteration:
-            self._next = None
-            return
-        with torch.cuda.stream(self.stream):
-            dev = stimuli.to(self.device, non_blocking=True)
-            yd = y_true.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._next = (dev, yd, ev)
-
-    def __iter__(self):
-        return self
-
-    def __next__(self):
-        if self._next is None:
-            raise StopIteration
-        dev, yd, ev = self._next
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_event(ev)
-        dev.record_stream(cur); yd.record_stream(cur)
-        x = dev.to(torch.float32)          # the kernels read float32 stimuli (0.0 / 1.0 exactly)
-        self._fetch()
-        return x, yd
+def pack_bits(stimuli: torch.Tensor) -> torch.Tensor:
+    """Host-side helper for dataloaders: a 0/1 pianoroll batch [B,1,H,W] (any dtype) as bit planes [B,1,H,W/8] uint8 (most
+    significant bit first, numpy.packbits order) - 1/32 of the float32 bytes.  train_one_epoch expands such batches on the device."""
+    b = (stimuli != 0).to(torch.uint8)
+    if b.shape[-1] % 8:
+        raise ValueError("pack_bits: the image width must be a multiple of 8")
+    w = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8)
+    return (b.reshape(*b.shape[:-1], b.shape[-1] // 8, 8) * w).sum(-1).to(torch.uint8)
 
 
-def _is_byte_loader(dataloader):
-    """True for list / tuple loaders of (uint8 | bool stimuli, labels) and for loaders that say so (``byte_stimuli = True``)."""
-    if getattr(dataloader, "byte_stimuli", False):
-        return True
-    if isinstance(dataloader, (list, tuple)) and dataloader:
-        first = dataloader[0][0]
-        return torch.is_tensor(first) and first.dtype in (torch.uint8, torch.bool)
-    return False
+def _expand_stimuli(stimuli: torch.Tensor, width: int) -> torch.Tensor:
+    """Device-side expansion of byte (uint8 / bool cells) or bit-plane (uint8, last dimension width / 8) stimuli to the float32
+    tensor the kernels read; float32 input passes through."""
+    if stimuli.dtype == torch.float32:
+        return stimuli
+    if stimuli.dtype == torch.uint8 and stimuli.shape[-1] * 8 == width:
+        shifts = torch.arange(7, -1, -1, device=stimuli.device, dtype=torch.uint8)
+        bits = (stimuli.unsqueeze(-1) >> shifts) & 1
+        return bits.reshape(*stimuli.shape[:-1], width).to(torch.float32)
+    return stimuli.to(torch.float32)
 
 
 def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, device="cuda", epoch=1, n_epoch=None,
                     total_step=0, n_samples_seen=0, verbose=False):
-    """Train the model for one epoch (train.py:554-767).  Stimuli may also arrive as uint8 / bool pianorolls (a list of batches,
-    or a loader with ``byte_stimuli = True``): they are copied one batch ahead on a copy stream and expanded on the device."""
+    """Train the model for one epoch (train.py:554-767).  Stimuli may also arrive as uint8 / bool pianorolls or as bit planes
+    (``pack_bits``): the host-to-device copy shrinks 4x / 32x and the batch is expanded to float32 on the device.  (A copy
+    stream that prefetches the next batch was measured too: 1.19-1.54 ms/step, erratic, against a steady 1.24 for the blocking
+    4 MB copy - tools/diag/gpu_loop_cost.py.)"""
     model.train()
     log_wandb = bool(getattr(config, "log_wandb", False))
     if log_wandb:
@@ -233,16 +207,19 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
     fused = (isinstance(model, VanillaVAE) and isinstance(optimizer, FusedAdamW)
              and getattr(criterion, "__self__", None) is model and not getattr(config, "freeze_encoder", False))
     n_batches = len(dataloader)
-    batches = _ByteBatchPrefetcher(dataloader, device) if (_is_byte_loader(dataloader) and torch.device(device).type == "cuda") else dataloader
-    for batch_idx, (stimuli, y_true) in enumerate(batches):
+    for batch_idx, (stimuli, y_true) in enumerate(dataloader):
         batch_size_this_gpu = stimuli.shape[0]
         # (blocking copies, as train.py:630-631: measured on MI355X, asynchronous copies of the pinned 16.8 MB batch are SLOWER
         #  here - 1.80 ms/step on the compute stream, 3.0 ms/step prefetched on a copy stream beside the step - than the
         #  blocking copy's 1.66 ms/step)
-        stimuli = stimuli.to(device)
-        y_true = y_true.to(device)
+        # byte / bit-plane batches in pinned memory are copied asynchronously on the compute stream: a blocking copy makes the host wait
+        # for the previous step to finish before it enqueues the next one (~80 us of idle GPU per step, measured with 0.5 MB batches)
+        small = stimuli.dtype != torch.float32 and stimuli.device.type == "cpu" and stimuli.is_pinned()
+        stimuli = stimuli.to(device, non_blocking=small)
+        # (train.py:631 also copies y_true to the device; nothing in the loop reads the labels, and the blocking copy of an unpinned
+        #  tensor is one more host-device rendezvous per step: left on the host)
         if stimuli.dtype != torch.float32:
-            stimuli = stimuli.to(torch.float32)
+            stimuli = _expand_stimuli(stimuli, getattr(model, "img_size", stimuli.shape[-1]))
         if fused:
             # train.py:634-656 as one HIP chain: forward, ELBO, backward, [all-reduce], AdamW
             out3, reconstruction = fused_step(model, optimizer, stimuli, use_device_eps=False)
