@@ -96,7 +96,7 @@ extern "C" int64_t vae_workspace_bytes(const vae_ctx* c) { return c ? c->ws_byte
 
 extern "C" vae_ctx* vae_create(int H, int L, int maxB, int dtype, int gen) {
     vae_ctx* c = new vae_ctx();
-    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 2; c->knob_convout_grid = 1536; c->knob_convout_bwd_grid = 1024; c->knob_down_per_cu = 2; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 2; c->knob_down_waves = 8; c->knob_pack_grid = 128; c->knob_xcd_map = 1; c->knob_up_nt_max = 1; c->knob_lay42 = 1; c->knob_wgrad_layer_wgs = 0; c->knob_conv1_grid = 1024; c->use_fused_bn = 1; c->knob_rev = 4; c->knob_lean = 1; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
+    c->H = H; c->L = L; c->maxB = maxB; c->dtype = dtype; c->gen = gen; c->ws_bytes = 0; c->use_tr16 = 1; c->use_mfma_convout = 1; c->use_pipelined = 1; c->knob_up_per_cu = 2; c->knob_convout_grid = 1536; c->knob_convout_bwd_grid = 1024; c->knob_down_per_cu = 2; c->knob_nt_max = 4; c->knob_pipe_max_cout = 256; c->knob_ablate_b = 0; c->use_side_stream = 1; c->knob_bwd_per_cu = 0; c->knob_wave_nt_max = 4; c->knob_lay22_min_nt = 2; c->knob_down_waves = 8; c->knob_pack_grid = 128; c->knob_xcd_map = 1; c->knob_up_nt_max = 1; c->knob_lay42 = 1; c->knob_wgrad_layer_wgs = 0; c->knob_conv1_grid = 512; c->use_fused_bn = 1; c->knob_rev = 4; c->knob_lean = 1; c->walk_dir = 0; c->n_side_ok = 0; c->side_rr = 0; c->fork_rr = 0; c->comm_busy = 0; c->dbg_buf = nullptr; c->dbg_tag[0] = 0; c->dbg_epi = 0;
     if (getenv("VAE_NO_SIDE_STREAM")) c->use_side_stream = 0;   // diagnostics: everything on the caller's stream
     c->packed_for = nullptr; c->bwd_dirty = 1; c->bwd_half_done = 0; c->B = 0; c->trained = 0; c->prof = 0; c->tag = nullptr;
     if (vae_param_layout(H, L, gen, c->poff, c->psz, &c->ptotal) != 0) { delete c; return nullptr; }
