@@ -1125,6 +1125,39 @@ def test_library_allreduce_single_rank_rccl():
     assert b"no communicator" in _lib.lib().vae_last_error()
 
 
+@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
+def test_streaming_first_conv_matches_tiled_kernel(dtype, B):
+    """encoder.1's forward on 128x128 images runs as a row-streaming kernel (dnfirst_stream.cuh: LDS-DMA ring in even / odd pixel planes,
+    transposed MFMAs with the weights in registers).  Same products and rounding points as the tiled kernel (down2_kernel); the f32
+    accumulation runs in two interleaved chains and adds the bias last, so a few stored values per 10^5 round the other way by one
+    storage ulp and everything downstream follows at that level."""
+    from torch_vae_amd import _lib
+    H, L = 128, 16
+    p = perturbed_params(L, H, 22, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 9)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 9, 5).reshape(B, L)).float().cuda()
+    res = []
+    for stream in (0, 1):
+        m = make_model(H, L, True, dtype, p, kld_weight=1.0)
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_dnf_stream", stream), "set")
+        out3, xhat = m.fused_forward_backward(x, eps=eps)
+        n = B * 64 * (H // 4) ** 2
+        y1 = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 1, y1.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        torch.cuda.synchronize()
+        res.append((out3.cpu().numpy(), xhat.cpu().numpy(), y1.cpu().numpy(), m.flat_grads().cpu().numpy(), m._bnflat.cpu().numpy()))
+    (o0, x0, y0, g0, b0), (o1, x1, y1, g1, b1) = res
+    frac = float((y0 != y1).mean())
+    ulp = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}[dtype]
+    excess = float((np.abs(y0 - y1) - 1.01 * ulp * np.abs(y0)).max() / np.abs(y0).max())
+    report(test="streaming_first_conv", dtype=dtype, batch=B, differing_fraction=frac, excess_over_one_ulp=excess, grads=rel_l2(g1, g0))
+    assert frac < 2e-3 and excess <= 1e-6, (frac, excess)
+    np.testing.assert_allclose(o1, o0, rtol=5e-5)
+    assert float(np.abs(x1 - x0).max()) < 5e-3      # (seven layers downstream of the perturbed roundings: measured 1.3e-3 in f16)
+    assert rel_l2(b1, b0) < 1e-5
+    assert rel_l2(g1, g0) < {"bf16": 1e-2, "f16": 5e-3}[dtype], rel_l2(g1, g0)
+
+
 @pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 9), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
 def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
     """final_layer.0's forward on 128x128 images runs as a row-streaming kernel (upfinal_stream.cuh: LDS-DMA ring, transposed MFMAs,

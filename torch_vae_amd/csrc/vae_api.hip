@@ -236,6 +236,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "use_convout_stream")) { c->use_convout_stream = value; return 0; }
     if (!strcmp(name, "use_wgrad_split")) { c->use_wgrad_split = value; return 0; }
     if (!strcmp(name, "use_upf_stream")) { c->use_upf_stream = value; return 0; }
+    if (!strcmp(name, "use_dnf_stream")) { c->use_dnf_stream = value; return 0; }
     if (!strcmp(name, "knob_convout_bands")) { c->knob_convout_bands = value; return 0; }
     if (!strcmp(name, "knob_convout_step_grid")) { c->knob_convout_step_grid = value > 0 ? value : 1; return 0; }
     if (!strcmp(name, "knob_ablate_f")) { c->knob_ablate_f = value; return 0; }

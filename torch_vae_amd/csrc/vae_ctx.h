@@ -109,6 +109,7 @@ struct vae_ctx {
     // finalisation that kernel's prologue performs; loss_out3 / loss_kw: where vae_loss_deferred wants the ELBO scalars.
     int use_fused_convout = 1, convout_pending = 0, dlogit_valid = 0;
     // use_convout_stream: 128-pixel-wide images take the row-streaming form of that kernel (convout_stream.cuh); 0 = the tiled one
+    int use_dnf_stream = 1;    // encoder.1 forward on 128x128 images: row-streaming kernel (dnfirst_stream.cuh); 0 = the tiled one
     int use_upf_stream = 1;    // final_layer.0 forward on 128x128 images: row-streaming kernel (upfinal_stream.cuh); 0 = the tiled one
     int use_wgrad_split = 1;   // deep weight gradients: producer / consumer wave groups (wgrad_split.cuh); 0 = the 8-wave kernel
     int use_convout_stream = 1, knob_convout_bands = 0;   // (bands per image: 0 = chosen by the launcher)

@@ -11,6 +11,7 @@
 #include "convout_stream.cuh"
 #include "wgrad_split.cuh"
 #include "upfinal_stream.cuh"
+#include "dnfirst_stream.cuh"
 
 // ---------------------------------------------------------------------------
 template <typename K> static int set_lds(K kernel, size_t bytes) {
@@ -80,6 +81,27 @@ static int launch_conv_deep(vae_ctx* c, ConvArgs<T> a, bool is_down, hipStream_t
 
 template <typename T>
 static int launch_down(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        // encoder.1's forward on 128x128 images: the row-streaming kernel (dnfirst_stream.cuh)
+        if (c->use_dnf_stream && a.epi == EPI_FWD && a.Cin == 32 && a.Cout == 64 && a.Hs == dfs::HO && a.Ws == dfs::WO && !a.stage_out && !a.two_src) {
+            DnFirstStreamArgs<T> m;
+            m.yin = a.src0; m.coef = a.coef; m.slope = a.slope; m.fuse = a.fuse; m.wp = a.wp; m.bias = a.bias; m.out = a.out; m.stat = a.stat; m.B = a.B;
+            const int ncu = 256;
+            long best = -1; int nb = 1;
+            for (int cand = 1; cand <= 8 && dfs::HO / cand >= 4; cand *= 2) {
+                const long rounds = ((long)a.B * cand + ncu - 1) / ncu, cost = rounds * (dfs::HO / cand / 2 + 2);
+                if (best < 0 || cost < best) { best = cost; nb = cand; }
+            }
+            m.nb = nb; m.RB = dfs::HO / nb; m.n_units = a.B * nb;
+            const double px_out = (double)a.B * a.Hs * a.Ws;
+            ProfScope ps(c, "down_fwd(conv)", sizeof(T) * (4 * px_out * 32 + px_out * 64 + 9.0 * 32 * 64), 2.0 * 9 * 32 * 64 * px_out, st);
+            const size_t lds = dnfirst_stream_lds();
+            if (set_lds(dnfirst_stream_kernel<T>, lds)) return -1;
+            hipLaunchKernelGGL((dnfirst_stream_kernel<T>), dim3(std::min(m.n_units, ncu)), dim3(768), lds, st, m);
+            LAUNCH_CHECK("dnfirst_stream_kernel");
+            return 0;
+        }
+    }
     if (c->use_pipelined) { const int rc = launch_conv_deep<T>(c, a, true, st); if (rc <= 0) return rc; }
     if (c->use_pipelined && a.Cout <= c->knob_pipe_max_cout && fits_i32(a)) return launch_conv_pipe<T>(c, a, true, st);
     Tiling t = make_tiling(a.Hs, a.Ws, 128);
