@@ -1158,10 +1158,11 @@ def test_streaming_first_conv_matches_tiled_kernel(dtype, B):
     assert rel_l2(g1, g0) < {"bf16": 1e-2, "f16": 5e-3}[dtype], rel_l2(g1, g0)
 
 
-@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 9), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
-def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
+@pytest.mark.parametrize("bit,which", [(1, 7), (2, 6)])      # final_layer.0 (default on), decoder.2 (same template, 64 input channels; off by default: no gain)
+@pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
+def test_streaming_final_convt_matches_tiled_kernel(dtype, B, bit, which):
     """final_layer.0's forward on 128x128 images runs as a row-streaming kernel (upfinal_stream.cuh: LDS-DMA ring, transposed MFMAs,
-    bands of rows per workgroup).  Same products and the same rounding points as the tiled kernel (up2_kernel); the f32 accumulation
+    bands of rows per workgroup); the same template also covers decoder.2 (64 input channels, 32-pixel rows; off by default: no gain).  Same products and the same rounding points as the tiled kernel (up2_kernel); the f32 accumulation
     visits the taps in another order and adds the bias last, so a few stored values per 10^5 round the other way (measured
     0.003-0.04 %, always by one storage ulp) and everything downstream follows at that level."""
     from torch_vae_amd import _lib
@@ -1172,11 +1173,11 @@ def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
     res = []
     for stream in (0, 1):
         m = make_model(H, L, True, dtype, p, kld_weight=1.0)
-        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_upf_stream", stream), "set")
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_upf_stream", bit * stream), "set")
         out3, xhat = m.fused_forward_backward(x, eps=eps)
-        n = B * 32 * H * H
+        n = B * 32 * (H if which == 7 else H // 2) ** 2
         y7 = torch.empty(n, device="cuda")
-        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 7, y7.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, which, y7.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
         torch.cuda.synchronize()
         res.append((out3.cpu().numpy(), xhat.cpu().numpy(), y7.cpu().numpy(), m.flat_grads().cpu().numpy(), m._bnflat.cpu().numpy()))
     (o0, x0, y0, g0, b0), (o1, x1, y1, g1, b1) = res
@@ -1185,7 +1186,7 @@ def test_streaming_final_convt_matches_tiled_kernel(dtype, B):
     # one storage rounding step where the value is of normal size; where the taps cancel (|y| tiny against its terms) the two
     # summation orders differ by f32 rounding of the terms instead: 1e-6 of the tensor's largest magnitude bounds that
     excess = float((np.abs(y0 - y1) - 1.01 * ulp * np.abs(y0)).max() / np.abs(y0).max())
-    report(test="streaming_final_convt", dtype=dtype, batch=B, differing_fraction=frac, excess_over_one_ulp=excess, grads=rel_l2(g1, g0))
+    report(test="streaming_final_convt", layer=which, dtype=dtype, batch=B, differing_fraction=frac, excess_over_one_ulp=excess, grads=rel_l2(g1, g0))
     assert frac < 2e-3 and excess <= 1e-6, (frac, excess)   # (measured 1e-8 .. 2.5e-8)
     np.testing.assert_allclose(o1, o0, rtol=2e-5)
     assert float(np.abs(x1 - x0).max()) < {"bf16": 5e-3, "f16": 1e-3}[dtype]

@@ -28,33 +28,45 @@ template <typename T> struct UpFinalStreamArgs {
 };
 
 namespace ufs {
-static constexpr int WL = 64, HL = 64, NRING = 12, YROW = WL * 64, AROW = (WL + 4) * 64, OPITCH = 72, OTILE = 64 * OPITCH, WBYTES = 9 * 4 * 32 * 16;
+// geometry of an instance: CIN input channels, WL x WL input pixels (32 output channels, 2 WL x 2 WL output pixels)
+template <int CIN, int WL_> struct Geo {
+    static constexpr int WL = WL_, HL = WL_, NCH = CIN / 8, PXB = CIN * 2, NKS = CIN / 16, NBR = WL / 32;
+    // copies run DD ticks ahead of the staging (the 64-channel instance keeps 36 KiB of weights in LDS and has room for one tick only)
+    static constexpr int NRING = 12, DD = CIN == 32 ? 2 : 1, NYR = 4 * (DD + 1);
+    static constexpr int YROW = WL * PXB, AROW = (WL + 1) * PXB, OPITCH = 72, OTILE = 64 * OPITCH, WBYTES = 9 * NCH * 32 * 16;
+    static_assert(WL * NCH == 256, "a row is 256 16-byte chunks (64 pixels x 32 channels or 32 pixels x 64 channels)");
+    // byte offset of chunk c of pixel px in a ring row: the XOR swizzle that makes 16 consecutive pixels' b128 reads conflict-free
+    __device__ static __forceinline__ int off(int px, int c) { return px * PXB + ((c ^ ((px >> (NCH == 4 ? 2 : 1)) & (NCH - 1))) << 4); }
+    static constexpr size_t lds() { return (size_t)NYR * YROW + (size_t)NRING * AROW + WBYTES + 8 * OTILE + (2 * CIN + 32) * 4; }
+};
+static constexpr int HL = 64, WL = 64;     // final_layer.0 (the launcher's names)
 }
-static inline size_t upfinal_stream_lds() { return (size_t)ufs::NRING * (ufs::YROW + ufs::AROW) + ufs::WBYTES + 8 * ufs::OTILE + 3 * 32 * 4; }
+template <int CIN, int WL> static inline size_t upfinal_stream_lds() { return ufs::Geo<CIN, WL>::lds(); }
 
-template <typename T>
+template <typename T, int CIN, int WL_>
 __global__ __launch_bounds__(1024) void upfinal_stream_kernel(UpFinalStreamArgs<T> a) {
-    using namespace ufs;
-    using cos::ring_off;
+    typedef ufs::Geo<CIN, WL_> GE;
+    constexpr int WL = GE::WL, HL = GE::HL, NCH = GE::NCH, PXB = GE::PXB, NKS = GE::NKS, NBR = GE::NBR;
+    constexpr int NRING = GE::NRING, DD = GE::DD, NYR = GE::NYR, YROW = GE::YROW, AROW = GE::AROW, OPITCH = GE::OPITCH, OTILE = GE::OTILE, WBYTES = GE::WBYTES;
     typedef typename H16<T>::v8 T8;
     typedef typename H16<T>::v2 T2;
     typedef __attribute__((ext_vector_type(4))) T T4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* yring = smem;                                   // raw y6 rows, filled by LDS-DMA
-    char* aring = yring + NRING * YROW;                   // LeakyReLU(BN(y6)), pixel 64 of every row stays zero
+    char* aring = yring + NYR * YROW;                     // LeakyReLU(BN(y)), the pad pixel at the right end of every row stays zero
     char* wlds = aring + NRING * AROW;                    // packed weights
     char* otile0 = wlds + WBYTES;                         // [8 waves][64 output pixels][72 B]
-    float* cf = reinterpret_cast<float*>(otile0 + 8 * OTILE);   // scale | shift | bias
+    float* cf = reinterpret_cast<float*>(otile0 + 8 * OTILE);   // scale[CIN] | shift[CIN] | bias[32]
     float* red = reinterpret_cast<float*>(otile0);        // final reduction [8][64] (the tiles are dead by then)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
     const int G = gridDim.x, K = a.RB / 4 + 2;
     const int wq = wave & 7;
 
-    if (tid < 32) {
-        if (a.fuse.mode != BNF_NONE) { float k1; bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], k1, cf[32 + tid]); }
-        else { cf[tid] = a.coef[tid]; cf[32 + tid] = a.coef[2 * 32 + tid]; }
-        cf[64 + tid] = a.bias[tid];
+    if (tid < CIN) {
+        if (a.fuse.mode != BNF_NONE) { float k1; bn_fused_channel(a.fuse, tid, blockIdx.x == 0, cf[tid], k1, cf[CIN + tid]); }
+        else { cf[tid] = a.coef[tid]; cf[CIN + tid] = a.coef[2 * CIN + tid]; }
     }
+    if (tid >= 64 && tid < 96) cf[2 * CIN + tid - 64] = a.bias[tid - 64];
     for (int i = tid; i < NRING * AROW / 16; i += 1024) *reinterpret_cast<f32x4*>(aring + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < WBYTES / 16; i += 1024) *reinterpret_cast<f32x4*>(wlds + i * 16) = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.wp) + i * 16);
 
@@ -70,39 +82,39 @@ __global__ __launch_bounds__(1024) void upfinal_stream_kernel(UpFinalStreamArgs<
             if (live) {
                 const int row = r0a - 3 + 4 * ka + drow, r1 = r0a + a.RB;
                 const bool ok = row >= r0a && row < HL && row <= r1;
-                const char* rowp = reinterpret_cast<const char*>(a.yin + ((size_t)(ba * HL + (ok ? row : 0)) * WL) * 32);
-                int slot = ya + drow; slot = slot >= NRING ? slot - NRING : slot;
+                const char* rowp = reinterpret_cast<const char*>(a.yin + ((size_t)(ba * HL + (ok ? row : 0)) * WL) * CIN);
+                int slot = ya + drow; slot = slot >= NYR ? slot - NYR : slot;
                 char* dst = yring + slot * YROW + (wq & 1) * 2048;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int ci = dci + 64 * j, px = ci >> 2, ch = (ci & 3) ^ ((px >> 2) & 3);   // the chunk stored at linear position ci
-                    cos::dma16(rowp + px * 64 + ch * 16, dst + j * 1024);
+                    const int ci = dci + 64 * j, px = ci / NCH, cs = ci % NCH;             // linear position ci = (pixel, stored slot)
+                    cos::dma16(rowp + GE::off(px, cs), dst + j * 1024);                    // (source chunk = slot ^ swizzle: off() is an involution on the slot)
                 }
             }
-            ya = ya + 4 >= NRING ? ya + 4 - NRING : ya + 4;
+            ya = ya + 4 >= NYR ? ya + 4 - NYR : ya + 4;
             if (++ka == K) {
                 ka = 0; ua += G;
                 if (ua < a.n_units) { ba = ua / a.nb; r0a = (ua - ba * a.nb) * a.RB; }
             }
             return live ? 2 : 0;
         };
-        issue_ahead();
-        const int nd1 = issue_ahead();
+        int nd1 = issue_ahead();             // tick 0 (and, two ticks ahead, tick 1: then its copies may stay in flight while tick 0's land)
+        if (DD == 2) nd1 = issue_ahead(); else nd1 = 0;
         deep::barrier_lds();                 // cf, zeroed a ring, weights published
         // staging: chunks st and st + 512 of the tick's 4 x 256 (row = chunk >> 8: rows 0,1 and 2,3; same pixel and channels for both)
         const int st = tid & 511, srow = st >> 8, spos = (st & 255) * 16;
         f32x2 kc[4], kh[4];
         {
-            const int px = (st & 255) >> 2, ch = (st & 3) ^ ((px >> 2) & 3);
+            const int pos = st & 255, px = pos / NCH, ch = (GE::off(px, pos % NCH) - px * PXB) >> 4;   // the channel chunk stored at this position
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 kc[e] = f32x2{cf[ch * 8 + 2 * e], cf[ch * 8 + 2 * e + 1]};
-                kh[e] = f32x2{cf[32 + ch * 8 + 2 * e], cf[32 + ch * 8 + 2 * e + 1]};
+                kh[e] = f32x2{cf[CIN + ch * 8 + 2 * e], cf[CIN + ch * 8 + 2 * e + 1]};
             }
         }
         cos::wait_vm(nd1);
         deep::barrier_lds();
-        int py = 0;                          // ring slot of row sB (y and a rings move together)
+        int py = 0, pyy = 0;                 // a-ring / y-ring slot of row sB
         for (int unit = blockIdx.x; unit < a.n_units; unit += G) {
             const int r0 = (unit % a.nb) * a.RB, r1 = r0 + a.RB;
             for (int k = 0; k < K; ++k) {
@@ -113,9 +125,10 @@ __global__ __launch_bounds__(1024) void upfinal_stream_kernel(UpFinalStreamArgs<
                     const int row = sB + srow + 2 * u;
                     const bool ok = row >= r0 && row < HL && row <= r1;
                     int slot = py + srow + 2 * u; slot = slot >= NRING ? slot - NRING : slot;
+                    int yslot = pyy + srow + 2 * u; yslot = yslot >= NYR ? yslot - NYR : yslot;
                     char* adst = aring + slot * AROW + spos;
                     if (!ok) { *reinterpret_cast<T8*>(adst) = T8{0, 0, 0, 0, 0, 0, 0, 0}; continue; }   // (wave-uniform) outside the image / band: a = 0
-                    const T8 yv = *reinterpret_cast<const T8*>(yring + slot * YROW + spos);
+                    const T8 yv = *reinterpret_cast<const T8*>(yring + yslot * YROW + spos);
                     T8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -126,24 +139,26 @@ __global__ __launch_bounds__(1024) void upfinal_stream_kernel(UpFinalStreamArgs<
                     }
                     *reinterpret_cast<T8*>(adst) = o;
                 }
-                cos::wait_vm(nd);            // the next tick's copies landed (only this tick's, issued after them, may be outstanding)
+                cos::wait_vm(DD == 2 ? nd : 0);   // the next tick's copies landed (two ticks ahead: only this tick's, issued after them, may be outstanding)
                 deep::barrier_lds();
-                py = py + 4 >= NRING ? py + 4 - NRING : py + 4;
+                py = py + 4 >= NRING ? py + 4 - NRING : py + 4; pyy = pyy + 4 >= NYR ? pyy + 4 - NYR : pyy + 4;
             }
         }
     } else {
         // ====================================== group A: MFMAs, epilogue, stores ======================================
-        const int arow = wave >> 1, x0 = (wave & 1) * 32;          // this wave's block: input row sA + arow, pixels x0 .. x0 + 31
+        // this wave's work: input row sA + arow and - 64-pixel rows - the block of 32 pixels x0 .. (both output rows of it), or - 32-pixel
+        // rows - the whole row and ONE of its two output rows
+        const int arow = wave >> 1, x0 = NBR == 2 ? (wave & 1) * 32 : 0, pysel = wave & 1;
         char* otile = otile0 + wave * OTILE;
         // B fragments: a[pixel x0 + r + dx][channels 16 ks + 8h ..]
-        int offB[2][2];
+        int offB[2][NKS];
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) offB[dx][ks] = ring_off(x0 + r + dx, 2 * ks + h);
-        const int offWt = h * 512 + r * 16;                        // A fragment of (tap t, k-step ks): wlds + (t * 4 + 2 ks) * 512 + offWt
+            for (int ks = 0; ks < NKS; ++ks) offB[dx][ks] = GE::off(x0 + r + dx, 2 * ks + h);
+        const int offWt = h * 512 + r * 16;                        // A fragment of (tap t, k-step ks): wlds + (t * NCH + 2 ks) * 512 + offWt
         deep::barrier_lds();
-        const float* biap = cf + 64 + 4 * h;                       // bias of the lane's channel pairs: acc_row(2e, lane) = 4h + 2 (e & 1) + 8 (e >> 1)
+        const float* biap = cf + 2 * CIN + 4 * h;                       // bias of the lane's channel pairs: acc_row(2e, lane) = 4h + 2 (e & 1) + 8 (e >> 1)
         f32x2 s1[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
@@ -162,18 +177,19 @@ __global__ __launch_bounds__(1024) void upfinal_stream_kernel(UpFinalStreamArgs<
                         return load_frag(reinterpret_cast<const T*>(row + offB[dx][ks]));
                     };
                     auto wfrag = [&](int t, int ks) __attribute__((always_inline)) {
-                        return load_frag(reinterpret_cast<const T*>(wlds + (t * 4 + 2 * ks) * 512 + offWt));
+                        return load_frag(reinterpret_cast<const T*>(wlds + (t * NCH + 2 * ks) * 512 + offWt));
                     };
                     T* orow_g = a.out + ((size_t)(b * 2 * HL + 2 * m) * (2 * WL) + 2 * x0) * 32;   // output row 2m, pixels 2 x0 ..
 #pragma unroll
                     for (int py_ = 0; py_ < 2; ++py_) {
+                        if (NBR == 1 && py_ != pysel) continue;     // (wave-uniform)
                         f32x16 acc[2];                              // output parity (py_, 0), (py_, 1)
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
 #pragma unroll
                             for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
+                        for (int ks = 0; ks < NKS; ++ks) {
                             // (m, n), (m, n+1) and - odd output rows - (m+1, n), (m+1, n+1) of this k-step; the fence keeps the other
                             // k-step's fragments out of the register file (the wave has 128 VGPRs)
                             const Frag<T> bm0 = bfrag(row0, 0, ks), bm1 = bfrag(row0, 1, ks);

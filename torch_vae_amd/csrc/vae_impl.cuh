@@ -127,21 +127,30 @@ template <typename T>
 static int launch_up(vae_ctx* c, ConvArgs<T> a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         // final_layer.0's forward on 128x128 images: the row-streaming kernel (upfinal_stream.cuh)
-        if (c->use_upf_stream && a.epi == EPI_FWD && a.Cin == 32 && a.Cout == 32 && a.Hs == ufs::HL && a.Ws == ufs::WL && !a.stage_out && !a.two_src) {
+        const bool upf7 = a.Cin == 32 && a.Hs == 64 && a.Ws == 64, upf6 = a.Cin == 64 && a.Hs == 32 && a.Ws == 32;   // final_layer.0 / decoder.2 at 128x128
+        // (decoder.2 - bit 1 of the option - measures the same 32 us as the tiled kernel: off by default)
+        if (a.epi == EPI_FWD && a.Cout == 32 && ((upf7 && (c->use_upf_stream & 1)) || (upf6 && (c->use_upf_stream & 2))) && !a.stage_out && !a.two_src) {
+            const int HLr = a.Hs;
             UpFinalStreamArgs<T> m;
             m.yin = a.src0; m.coef = a.coef; m.slope = a.slope; m.fuse = a.fuse; m.wp = a.wp; m.bias = a.bias; m.out = a.out; m.stat = a.stat; m.B = a.B;
             const int ncu = 256;
             long best = -1; int nb = 1;
-            for (int cand = 1; cand <= 8 && ufs::HL / cand >= 8; cand *= 2) {
-                const long rounds = ((long)a.B * cand + ncu - 1) / ncu, cost = rounds * (ufs::HL / cand / 4 + 2);
+            for (int cand = 1; cand <= 8 && HLr / cand >= 8; cand *= 2) {
+                const long rounds = ((long)a.B * cand + ncu - 1) / ncu, cost = rounds * (HLr / cand / 4 + 2);
                 if (best < 0 || cost < best) { best = cost; nb = cand; }
             }
-            m.nb = nb; m.RB = ufs::HL / nb; m.n_units = a.B * nb;
+            m.nb = nb; m.RB = HLr / nb; m.n_units = a.B * nb;
             const double px_in = (double)a.B * a.Hs * a.Ws;
-            ProfScope ps(c, "up_fwd(convT)", sizeof(T) * (px_in * 32 + 4 * px_in * 32 + 9.0 * 32 * 32), 2.0 * 9 * 32 * 32 * px_in, st);
-            const size_t lds = upfinal_stream_lds();
-            if (set_lds(upfinal_stream_kernel<T>, lds)) return -1;
-            hipLaunchKernelGGL((upfinal_stream_kernel<T>), dim3(std::min(m.n_units, ncu)), dim3(1024), lds, st, m);
+            ProfScope ps(c, "up_fwd(convT)", sizeof(T) * (px_in * a.Cin + 4 * px_in * 32 + 9.0 * a.Cin * 32), 2.0 * 9 * a.Cin * 32 * px_in, st);
+            if (upf7) {
+                const size_t lds = upfinal_stream_lds<32, 64>();
+                if (set_lds(upfinal_stream_kernel<T, 32, 64>, lds)) return -1;
+                hipLaunchKernelGGL((upfinal_stream_kernel<T, 32, 64>), dim3(std::min(m.n_units, ncu)), dim3(1024), lds, st, m);
+            } else {
+                const size_t lds = upfinal_stream_lds<64, 32>();
+                if (set_lds(upfinal_stream_kernel<T, 64, 32>, lds)) return -1;
+                hipLaunchKernelGGL((upfinal_stream_kernel<T, 64, 32>), dim3(std::min(m.n_units, ncu)), dim3(1024), lds, st, m);
+            }
             LAUNCH_CHECK("upfinal_stream_kernel");
             return 0;
         }
