@@ -20,7 +20,7 @@ def load(d, counter):
 
 
 # label prefix -> regex of the device kernel(s) that label launches first
-KERNEL_OF = [("convT_bwd_fused", r"convt_bwd_fused_kernel"), ("conv_bwd_fused", r"(?<![a-z_])conv_bwd_fused_kernel"), ("down_", r"(?<![a-z_])(down2?|dn3)_kernel"), ("up_", r"(?<![a-z_])(up2?|up3|upfinal_stream)_kernel"), ("wgrad_kernel", r"(?<![a-z_])wgrad(_split)?_kernel"),
+KERNEL_OF = [("convT_bwd_fused", r"convt_bwd_fused_kernel"), ("conv_bwd_fused", r"(?<![a-z_])conv_bwd_fused_kernel"), ("down_", r"(?<![a-z_])(down2?|dn3|dnfirst_stream)_kernel"), ("up_", r"(?<![a-z_])(up2?|up3|upfinal_stream)_kernel"), ("wgrad_kernel", r"(?<![a-z_])wgrad(_split)?_kernel"),
              ("convout_step", r"convout_(step|stream)"), ("convout_fwd", r"convout_fwd"), ("convout_bwd", r"convout_bwd"), ("conv1_fwd", r"conv1_fwd"),
              ("conv1_wgrad", r"conv1_wgrad"), ("dense", r"dense_kernel"), ("decin_fwd", r"decin_fwd|row_gemm_kernel"),
              ("decin_wgrad", r"decin_wgrad|batch_gemm_kernel"), ("fc_wgrad", r"fc_wgrad|batch_gemm_kernel"), ("fc_dgrad", r"fc_dgrad|row_gemm_kernel"), ("pack_weights", r"pack_kernel"),
