@@ -1158,6 +1158,33 @@ def test_streaming_first_conv_matches_tiled_kernel(dtype, B):
     assert rel_l2(g1, g0) < {"bf16": 1e-2, "f16": 5e-3}[dtype], rel_l2(g1, g0)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_streaming_forward_kernels_in_eval_mode(dtype):
+    """The streaming forward kernels (encoder.1, final_layer.0, decoder.2) with BatchNorm coefficients from RUNNING statistics (eval-mode
+    forward, evaluation.evaluate's path) instead of the fused batch-statistics finalisation: same output as the tiled kernels."""
+    from torch_vae_amd import _lib
+    H, L, B = 128, 16, 3
+    p = perturbed_params(L, H, 23, True)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 10)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 10, 5).reshape(B, L)).float().cuda()
+    outs = []
+    for stream in (0, 1):
+        m = make_model(H, L, True, dtype, p, kld_weight=1.0)
+        h = m._context(B).handle
+        _lib.check(_lib.lib().vae_set_option(h, b"use_upf_stream", 3 * stream), "set")
+        _lib.check(_lib.lib().vae_set_option(h, b"use_dnf_stream", stream), "set")
+        m.fused_forward_backward(x, eps=eps)          # one training step's forward: running statistics move away from (0, 1)
+        m.eval()
+        with torch.no_grad():
+            m.set_next_eps(eps)
+            out = m(x)
+        outs.append((out["output"].float().cpu().numpy(), out["encoded"]["mu"].float().cpu().numpy()))
+    (x0, mu0), (x1, mu1) = outs
+    np.testing.assert_allclose(mu1, mu0, rtol=2e-2, atol=2e-3)
+    assert float(np.abs(x1 - x0).max()) < 5e-3, float(np.abs(x1 - x0).max())
+    assert rel_l2(x1, x0) < 1e-3
+
+
 @pytest.mark.parametrize("bit,which", [(1, 7), (2, 6)])      # final_layer.0 (default on), decoder.2 (same template, 64 input channels; off by default: no gain)
 @pytest.mark.parametrize("dtype,B", [("bf16", 3), ("f16", 5), ("bf16", 40)])   # (40 images x 8 bands = 320 units: more than one per workgroup)
 def test_streaming_final_convt_matches_tiled_kernel(dtype, B, bit, which):
