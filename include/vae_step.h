@@ -184,6 +184,14 @@ int vae_train_step_fused(vae_ctx* ctx, const float* x, int batch, float* params,
  * (called as at :97-104), seeded; x [B,1,H,H] f32 in {0,1}.  Device-side generator. */
 int vae_synth_pianoroll(float* x, int batch, int img_size, uint64_t seed, vae_stream_t stream);
 
+/* Byte or bit-plane stimuli expanded to the float32 batch [B,1,H,W] the step reads (the host side of
+ * train.py:630-631: the reference copies float32 stimuli; a 0/1 pianoroll needs 1/4 or 1/32 of those
+ * bytes on the host link).  kind 0: one byte per cell, v -> (float)v; kind 1: bit planes, most
+ * significant bit first (numpy.packbits order).  `src` is device memory or PINNED host memory (read in
+ * place by the kernel; the caller keeps it alive and unchanged until the stream has passed this call);
+ * pageable host memory is refused.  n_cells = B*H*W, a multiple of 8. */
+int vae_expand_stimuli(const void* src, int kind, float* dst, int64_t n_cells, vae_stream_t stream);
+
 /* Per-kernel timing for bench.py's roofline line: when enabled every launch of the step is
  * bracketed by HIP events on the launch stream; the report is a JSON array with, per kernel name,
  * calls, total ms, and total ALGORITHMIC bytes / flops (operand tensors once). */

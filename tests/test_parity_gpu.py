@@ -430,6 +430,42 @@ def test_train_one_epoch_byte_stimuli_match_float_stimuli():
         assert torch.equal(out[0][1], o[1])
 
 
+def test_expand_stimuli_kernel_from_device_and_pinned_host_memory():
+    """include/vae_step.h: vae_expand_stimuli - bytes and bit planes to float32, bit for bit the torch expression, from device memory
+    and from pinned host memory read in place; pageable host memory, odd sizes and unknown kinds are refused."""
+    from torch_vae_amd import _lib
+    from torch_vae_amd.train import pack_bits, _expand_stimuli
+    Lb = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    for (B, H) in ((3, 32), (5, 128), (256, 128)):
+        cells = (torch.rand(B, 1, H, H, generator=g) < 0.3)
+        want01 = cells.float().cuda()
+        raw = torch.randint(0, 256, (B, 1, H, H), dtype=torch.uint8, generator=g)
+        planes = pack_bits(cells)
+        assert planes.shape == (B, 1, H, H // 8)
+        for place in (lambda t: t.cuda(), lambda t: t.pin_memory()):
+            for src, kind, want in ((cells.to(torch.uint8), 0, want01), (raw, 0, raw.float().cuda()), (planes, 1, want01)):
+                s = place(src.contiguous())
+                out = torch.full((B, 1, H, H), -7.0, device="cuda")
+                _lib.check(Lb.vae_expand_stimuli(s.data_ptr(), kind, out.data_ptr(), B * H * H, st), "vae_expand_stimuli")
+                torch.cuda.synchronize()
+                assert torch.equal(out, want)
+            # the host-side helper of the loop takes the same path (bool cells too)
+            assert torch.equal(_expand_stimuli(place(planes), H, device="cuda"), want01)
+            assert torch.equal(_expand_stimuli(place(cells), H, device="cuda"), want01)
+        assert torch.equal(_expand_stimuli(planes, H, device="cuda"), want01)      # pageable host memory: copied first
+    out = torch.zeros(64, device="cuda")
+    pageable = torch.zeros(64, dtype=torch.uint8)
+    assert Lb.vae_expand_stimuli(pageable.data_ptr(), 0, out.data_ptr(), 64, st) != 0
+    dev = pageable.cuda()
+    assert Lb.vae_expand_stimuli(dev.data_ptr(), 2, out.data_ptr(), 64, st) != 0
+    assert Lb.vae_expand_stimuli(dev.data_ptr(), 0, out.data_ptr(), 60, st) != 0
+    assert Lb.vae_expand_stimuli(None, 0, out.data_ptr(), 64, st) != 0
+    assert Lb.vae_expand_stimuli(dev.data_ptr(), 0, out.data_ptr(), 0, st) == 0
+    torch.cuda.synchronize()
+
+
 def test_pipelined_and_simple_conv_kernels_agree():
     """The persistent/prefetched conv kernels (conv_pipe.cuh; wave-independent tiles and the 2x2 wave layout) against
     the one-tile-per-workgroup ones.  f32: exact arithmetic, only the summation order of the BatchNorm statistics

@@ -81,6 +81,7 @@ def lib():
     _sig(L.vae_train_step_fused, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32,
                                        i32, i32, p, p, p, p, p, p])
     _sig(L.vae_synth_pianoroll, i32, [p, i32, i32, u64, p])
+    _sig(L.vae_expand_stimuli, i32, [p, i32, p, i64, p])
     _sig(L.vae_profile, i32, [p, i32])
     _sig(L.vae_profile_report, i32, [p, C.c_char_p, i64])
     _sig(L.vae_profile_sequence, i32, [p, C.c_char_p, i64])
@@ -97,7 +98,7 @@ EXPORTS = [
     "vae_last_error", "vae_abi_version", "vae_param_layout", "vae_bn_layout", "vae_create", "vae_destroy",
     "vae_workspace_bytes", "vae_forward", "vae_decode", "vae_pre_latents", "vae_last_eps", "vae_loss", "vae_loss_deferred", "vae_elbo_generic",
     "vae_backward", "vae_backward_part", "vae_comm_stream", "vae_comm_unique_id", "vae_comm_init", "vae_comm_world",
-    "vae_comm_destroy", "vae_allreduce_grads", "vae_broadcast_state", "vae_adamw_step", "vae_train_step", "vae_train_step_fused", "vae_synth_pianoroll", "vae_profile",
+    "vae_comm_destroy", "vae_allreduce_grads", "vae_broadcast_state", "vae_adamw_step", "vae_train_step", "vae_train_step_fused", "vae_synth_pianoroll", "vae_expand_stimuli", "vae_profile",
     "vae_profile_report", "vae_profile_sequence", "vae_profile_timeline", "vae_debug_stamps", "vae_debug_tensor",
     "vae_selftest_tr16", "vae_set_option",
 ]

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
         }
     };
     dma_step(0, 0, 0);
+    DSTAMP(10)
 
     int jb[MTW];
 #pragma unroll
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = ebv[nt];
     }
+    DSTAMP(11)
     // out-tile chunk u of this lane (wave-local chunk id = lane + 64u)
     int orel[OPL], opk[OPL];
 #pragma unroll
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(512) void dn3_kernel(DeepConvArgs<T> da, int n_pair
         opk[u] = (row * OPITCH + qq * 16) | (img << 20);
     }
     decltype(Vec16<T>::v) prey[EPI == EPI_BWD ? OPL : 1];
+    DSTAMP(12)
 
     deep::barrier_lds();
 

@@ -311,6 +311,51 @@ extern "C" int vae_synth_pianoroll(float* x, int B, int H, uint64_t seed, vae_st
 }
 
 
+// Byte / bit-plane stimuli -> the float32 batch the kernels read (train.py:630 copies float32 stimuli; pianorolls are 0/1 cells).
+// kind 0: one byte per cell (uint8 / bool), value v -> (float)v; kind 1: bit planes, most significant bit first (numpy.packbits
+// order), bit -> 0.f / 1.f.  The source may be device memory or PINNED host memory: the kernel then reads the batch straight over
+// the host link (0.5 MB of bit planes or 4 MB of bytes for 256 images of 128x128), which removes the separate copy and its
+// queue hand-over from the step's dependent chain.
+__global__ void expand_bytes_kernel(const uint32_t* __restrict__ src, float* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t w = __builtin_nontemporal_load(src + i);
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = f32x4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+    }
+}
+__global__ void expand_bits_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long nbytes) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nbytes; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t w = __builtin_nontemporal_load(src + i);
+        *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{(float)((w >> 7) & 1u), (float)((w >> 6) & 1u), (float)((w >> 5) & 1u), (float)((w >> 4) & 1u)};
+        *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{(float)((w >> 3) & 1u), (float)((w >> 2) & 1u), (float)((w >> 1) & 1u), (float)(w & 1u)};
+    }
+}
+extern "C" int vae_expand_stimuli(const void* src, int kind, float* dst, int64_t n_cells, vae_stream_t stream) {
+    if (!src || !dst) return vae_set_error("vae_expand_stimuli", "null pointer");
+    if (kind != 0 && kind != 1) return vae_set_error("vae_expand_stimuli", "kind must be 0 (bytes) or 1 (bit planes)");
+    if (n_cells < 0 || n_cells % 8) return vae_set_error("vae_expand_stimuli", "the number of cells must be a multiple of 8");
+    if (n_cells == 0) return 0;
+    // the address the device uses for the source: device memory as is, pinned host memory through its mapping; anything else
+    // (pageable host memory) is refused - a kernel must not dereference it
+    hipPointerAttribute_t at; memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, src) != hipSuccess) { (void)hipGetLastError(); return vae_set_error("vae_expand_stimuli", "the source is neither device nor pinned host memory"); }
+    const void* dsrc = nullptr;
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) dsrc = src;
+    else if (at.type == hipMemoryTypeHost && at.devicePointer) dsrc = at.devicePointer;
+    else return vae_set_error("vae_expand_stimuli", "the source is neither device nor pinned host memory");
+    if ((reinterpret_cast<uintptr_t>(dsrc) & 3) || (reinterpret_cast<uintptr_t>(dst) & 15)) return vae_set_error("vae_expand_stimuli", "source must be 4-byte, destination 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) {
+        const long n4 = n_cells / 4;
+        hipLaunchKernelGGL(expand_bytes_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(dsrc), dst, n4);
+    } else {
+        const long nb = n_cells / 8;
+        hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)std::min<long>((nb + 255) / 256, 2048)), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(dsrc), dst, nb);
+    }
+    LAUNCH_CHECK("expand_stimuli_kernel");
+    return 0;
+}
+
+
 // ---------------------------------------------------------------------------
 extern "C" int vae_forward(vae_ctx* c, const float* x, int B, const float* params, float* bn_running, int64_t* nbt,
                            const float* eps, uint64_t seed, int train, float* xhat, float* mu, float* lv, float* z, vae_stream_t stream) {

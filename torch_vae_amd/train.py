@@ -12,8 +12,8 @@ still runs through the same kernels via autograd.  With ``torch.distributed`` in
 from __future__ import annotations
 
 import os
-
 import time
+from collections import deque
 from contextlib import nullcontext
 
 import torch
@@ -178,12 +178,34 @@ def pack_bits(stimuli: torch.Tensor) -> torch.Tensor:
     return (b.reshape(*b.shape[:-1], b.shape[-1] // 8, 8) * w).sum(-1).to(torch.uint8)
 
 
-def _expand_stimuli(stimuli: torch.Tensor, width: int) -> torch.Tensor:
+def _expand_stimuli(stimuli: torch.Tensor, width: int, device=None) -> torch.Tensor:
     """Device-side expansion of byte (uint8 / bool cells) or bit-plane (uint8, last dimension width / 8) stimuli to the float32
-    tensor the kernels read; float32 input passes through."""
+    tensor the kernels read; float32 input passes through.  On a GPU this is one library kernel (include/vae_step.h:
+    vae_expand_stimuli) which also reads PINNED host batches in place - no separate host-to-device copy in the step's chain;
+    the caller keeps such a host batch alive until the stream has passed the kernel.  CPU tensors with no target device (and
+    cell counts that are not a multiple of 8) take the torch expression of the same mapping."""
     if stimuli.dtype == torch.float32:
-        return stimuli
-    if stimuli.dtype == torch.uint8 and stimuli.shape[-1] * 8 == width:
+        return stimuli if device is None else stimuli.to(device)
+    planes = stimuli.dtype == torch.uint8 and stimuli.shape[-1] * 8 == width
+    target = torch.device(device) if device is not None else stimuli.device
+    if target.type == "cuda" and stimuli.dtype in (torch.uint8, torch.bool):
+        n_cells = stimuli.numel() * (8 if planes else 1)
+        if not (stimuli.is_cuda or (stimuli.is_pinned() and stimuli.is_contiguous())):
+            stimuli = stimuli.to(target)          # pageable host memory: the ordinary (blocking) copy first
+        if n_cells % 8 == 0 and n_cells > 0:
+            from . import _lib
+            src = stimuli.contiguous()
+            if target.index is None:
+                target = torch.device("cuda", torch.cuda.current_device())
+            out = torch.empty(*src.shape[:-1], width if planes else src.shape[-1], dtype=torch.float32, device=target)
+            with torch.cuda.device(target):
+                _lib.check(_lib.lib().vae_expand_stimuli(src.data_ptr(), 1 if planes else 0, out.data_ptr(), n_cells,
+                                                         torch.cuda.current_stream(target).cuda_stream), "vae_expand_stimuli")
+            return out
+        stimuli = stimuli.to(target)
+    elif device is not None:
+        stimuli = stimuli.to(device)
+    if planes:
         shifts = torch.arange(7, -1, -1, device=stimuli.device, dtype=torch.uint8)
         bits = (stimuli.unsqueeze(-1) >> shifts) & 1
         return bits.reshape(*stimuli.shape[:-1], width).to(torch.float32)
@@ -207,19 +229,25 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
     fused = (isinstance(model, VanillaVAE) and isinstance(optimizer, FusedAdamW)
              and getattr(criterion, "__self__", None) is model and not getattr(config, "freeze_encoder", False))
     n_batches = len(dataloader)
+    in_flight = deque()   # pinned host batches a device kernel may still be reading, with the event that follows that kernel
     for batch_idx, (stimuli, y_true) in enumerate(dataloader):
         batch_size_this_gpu = stimuli.shape[0]
-        # (blocking copies, as train.py:630-631: measured on MI355X, asynchronous copies of the pinned 16.8 MB batch are SLOWER
-        #  here - 1.80 ms/step on the compute stream, 3.0 ms/step prefetched on a copy stream beside the step - than the
-        #  blocking copy's 1.66 ms/step)
-        # byte / bit-plane batches in pinned memory are copied asynchronously on the compute stream: a blocking copy makes the host wait
-        # for the previous step to finish before it enqueues the next one (~80 us of idle GPU per step, measured with 0.5 MB batches)
-        small = stimuli.dtype != torch.float32 and stimuli.device.type == "cpu" and stimuli.is_pinned()
-        stimuli = stimuli.to(device, non_blocking=small)
+        # float32 stimuli: the blocking copy of train.py:630-631 (measured on MI355X, asynchronous copies of the pinned 16.8 MB batch
+        # are SLOWER here - 1.80 ms/step on the compute stream, 3.0 ms/step prefetched on a copy stream - than its 1.66 ms/step).
+        # Byte / bit-plane stimuli: expanded by one library kernel, which reads a PINNED host batch in place (no copy command, no
+        # host wait: a blocking copy makes the host wait for the previous step before it enqueues the next one, ~80 us of idle GPU
+        # per step); the host batch is kept alive until the stream has passed that kernel.
         # (train.py:631 also copies y_true to the device; nothing in the loop reads the labels, and the blocking copy of an unpinned
         #  tensor is one more host-device rendezvous per step: left on the host)
-        if stimuli.dtype != torch.float32:
-            stimuli = _expand_stimuli(stimuli, getattr(model, "img_size", stimuli.shape[-1]))
+        host_batch = stimuli if (stimuli.dtype != torch.float32 and stimuli.device.type == "cpu" and stimuli.is_pinned()) else None
+        stimuli = _expand_stimuli(stimuli, getattr(model, "img_size", stimuli.shape[-1]), device=device)
+        if host_batch is not None and stimuli.is_cuda:
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(stimuli.device))
+            in_flight.append((host_batch, ev))
+            while in_flight and in_flight[0][1].query():
+                in_flight.popleft()
+            if len(in_flight) > 8:
+                in_flight.popleft()[1].synchronize()
         if fused:
             # train.py:634-656 as one HIP chain: forward, ELBO, backward, [all-reduce], AdamW
             out3, reconstruction = fused_step(model, optimizer, stimuli, use_device_eps=False)
