@@ -276,7 +276,7 @@ def train_one_epoch(config, model, optimizer, scheduler, criterion, dataloader, 
         first_verbose = epoch <= 1 and batch_idx == 0 and verbose
         if loss_epoch_dev is None:
             loss_epoch_dev = torch.zeros((), dtype=torch.float64, device=out3.device)
-        loss_epoch_dev += out3[0].double()
+        loss_epoch_dev.add_(out3[0])          # (float64 += float32 in one kernel: the operand is widened inside it)
         if (printing and rank0) or logging or first_verbose:
             loss_batch, loss_recon, loss_kld = out3.tolist()  # one D2H sync for the three .item() of train.py:672-674
         if first_verbose:
