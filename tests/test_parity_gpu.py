@@ -1194,6 +1194,35 @@ def test_streaming_first_conv_matches_tiled_kernel(dtype, B):
     assert rel_l2(g1, g0) < {"bf16": 1e-2, "f16": 5e-3}[dtype], rel_l2(g1, g0)
 
 
+@pytest.mark.parametrize("dtype,H,L,B,gen", [("bf16", 128, 16, 37, True), ("f16", 64, 128, 70, True), ("bf16", 32, 10, 5, False), ("f16", 32, 16, 256, False)])
+def test_wide_fc_input_gradient_matches_one_channel_per_thread_kernel(dtype, H, L, B, gen):
+    """fc_mu | fc_var input gradient with 16-byte accesses (edge_kernels.cuh: fc_dgrad8_kernel, 8 channels x 4 rows per thread) against
+    the one-channel-per-thread kernel: the stored dz of encoder.3 is bit-identical (same fma chain per element); its BatchNorm
+    statistics are summed in another order, so the encoder gradients downstream agree to rounding."""
+    from torch_vae_amd import _lib
+    p = perturbed_params(L, H, 31, gen)
+    x = torch.from_numpy(vo.synth_pianoroll(B, H, 14)).cuda()
+    eps = torch.from_numpy(vo.counter_normal(B * L, 14, 5).reshape(B, L)).float().cuda()
+    res = []
+    for wide in (0, 1, 3):     # one channel per thread; 256-thread workgroups over 32 rows; 512-thread workgroups over 64 rows
+        m = make_model(H, L, gen, dtype, p, kld_weight=1.0)
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, b"use_fc_dgrad8", wide), "set")
+        out3, xhat = m.fused_forward_backward(x, eps=eps)
+        s = (H // 16) if gen else 2
+        n = B * 256 * s * s
+        dz3 = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, 11, dz3.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "dbg")
+        torch.cuda.synchronize()
+        res.append((out3.cpu().numpy(), dz3.cpu().numpy(), m.flat_grads().cpu().numpy()))
+    (o0, d0, g0) = res[0]
+    assert np.abs(d0).max() > 0
+    for (o1, d1, g1) in res[1:]:
+        assert np.array_equal(o0, o1)
+        assert np.array_equal(d0, d1)
+        report(test="wide_fc_dgrad", dtype=dtype, img=H, latent=L, batch=B, grads=rel_l2(g1, g0))
+        assert rel_l2(g1, g0) < {"bf16": 5e-3, "f16": 2e-3}[dtype], rel_l2(g1, g0)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_streaming_forward_kernels_in_eval_mode(dtype):
     """The streaming forward kernels (encoder.1, final_layer.0, decoder.2) with BatchNorm coefficients from RUNNING statistics (eval-mode

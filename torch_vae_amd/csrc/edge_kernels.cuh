@@ -569,6 +569,96 @@ __global__ __launch_bounds__(256) void fc_dgrad_kernel(FcDgradArgs<T> a) {
     unsafeAtomicAdd(&a.stat[stat_rep() * 512 + 256 + c], (double)s2);
 }
 
+// The same product for 16-bit storage with 16-byte accesses: a thread owns 8 consecutive channels (one 16-byte group of the packed
+// weight image, of y and of dz) and 4 batch rows, a workgroup 256 channels x 32 rows.  fc_dgrad_kernel moves two bytes per lane and
+// memory instruction (64 of them per thread and 16 rows: it is bound by their issue, ~20 us for 16 MB); here 8 rows x channels cost
+// one instruction.  Per element the arithmetic is fc_dgrad_kernel's (the same fma chain over j, the same epilogue expressions), so
+// the stored dz is bit-identical; the statistics are summed in a different order.
+template <typename T, int RT, int NRG>
+__global__ __launch_bounds__(32 * NRG) void fc_dgrad8_kernel(FcDgradArgs<T> a) {
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    static_assert(RT == 2 || RT == 4, "rows per thread");
+    typedef typename H16<T>::v8 T8;
+    constexpr int RB = NRG * RT, NTH = 32 * NRG;                     // rows per workgroup pass (NRG row groups x RT rows per thread)
+    extern __shared__ __attribute__((aligned(16))) float dl8_s[];    // [L2][RB], then red[NRG][256][2]
+    float* red = dl8_s + a.L2 * RB;
+    const int tid = threadIdx.x, g = tid & 31, rg = tid >> 5, c0 = g * 8, f0 = blockIdx.x * 256 + c0;
+    float sc[8], sh[8], is[8], xm[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = a.ocoef[LC_SC * 256 + c0 + e]; sh[e] = a.ocoef[LC_SH * 256 + c0 + e];
+        is[e] = a.ocoef[LC_INVSTD * 256 + c0 + e]; xm[e] = a.ocoef[LC_XM * 256 + c0 + e];
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const T* wrow = a.wp + (size_t)(f0 >> 3) * a.npad * 8;
+    const int bend = min(a.B, (int)(blockIdx.y + 1) * a.bt_per_wg);
+    for (int b0 = blockIdx.y * a.bt_per_wg; b0 < bend; b0 += RB) {
+        __syncthreads();
+        for (int i = tid; i < a.L2 * RB; i += NTH) {
+            const int bb = i / a.L2, j = i - bb * a.L2;              // (consecutive threads read consecutive floats of a dlat row)
+            dl8_s[j * RB + bb] = (b0 + bb < bend) ? a.dlat[(size_t)(b0 + bb) * a.L2 + j] : 0.f;
+        }
+        __syncthreads();
+        T8 yv[RT];
+        float acc[RT][8];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int b = b0 + rg * RT + r;
+            yv[r] = *reinterpret_cast<const T8*>(a.y + (size_t)(b < bend ? b : b0) * a.F + f0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
+        }
+        // eight weight groups in flight per block of the (sequential) j chain: one load per j costs the cache latency per j
+        for (int j0 = 0; j0 < a.L2; j0 += 8) {
+            T8 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const T8*>(wrow + (size_t)min(j0 + u, a.L2 - 1) * 8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < a.L2) {
+                    float d[RT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) d[r] = dl8_s[(j0 + u) * RB + rg * RT + r];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[r][e] += d[r] * tofloat((T)w[u][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int b = b0 + rg * RT + r;
+            if (b < bend) {
+                T8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float da = acc[r][e];
+                    if (a.gpre) da += a.gpre[(size_t)b * a.F + fref_of(f0 + e, a.s2)] * a.gmul;
+                    const float y = tofloat((T)yv[r][e]);
+                    const float z = y * sc[e] + sh[e];
+                    const float dzv = round_as<T>(z > 0.f ? da : da * a.slope);
+                    o[e] = fromfloat<T>(dzv);
+                    s1[e] += dzv; s2[e] += dzv * (y * is[e] + xm[e]);
+                }
+                *reinterpret_cast<T8*>(a.dz + (size_t)b * a.F + f0) = o;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(rg * 256 + c0 + e) * 2] = s1[e]; red[(rg * 256 + c0 + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    if (tid < 256) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NRG; ++k) { v1 += red[(k * 256 + tid) * 2]; v2 += red[(k * 256 + tid) * 2 + 1]; }
+        unsafeAtomicAdd(&a.stat[stat_rep() * 512 + tid], (double)v1);
+        unsafeAtomicAdd(&a.stat[stat_rep() * 512 + 256 + tid], (double)v2);
+    }
+}
+static inline size_t fc_dgrad8_lds(int L2, int RT, int NRG) { return ((size_t)L2 * NRG * RT + NRG * 256 * 2) * 4; }
+
 // dW_mu / dW_var [L][F_ref] = dlat^T @ a4  (K = batch)
 template <typename T> struct FcWgradArgs {
     const float* dlat; const T* y; const float* coef; float slope;

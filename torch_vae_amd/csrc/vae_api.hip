@@ -232,6 +232,7 @@ extern "C" int vae_set_option(vae_ctx* c, const char* name, int value) {
     if (!strcmp(name, "knob_lean")) { c->knob_lean = value; return 0; }   // bit 0: noise beside conv1; 1: BN backward inside conv1_wgrad; 2: deferred loss on a side stream
     if (!strcmp(name, "use_fused_wgrad")) { c->use_fused_wgrad = value == 1 ? 3 : (value == 2 ? 1 : (value == 3 ? 2 : 0)); return 0; }   // 1 all, 2 decoder side only, 3 encoder.1 only
     if (!strcmp(name, "use_recomp_dz")) { c->use_recomp_dz = value; return 0; }
+    if (!strcmp(name, "use_fc_dgrad8")) { c->use_fc_dgrad8 = value; return 0; }
     if (!strcmp(name, "use_fused_convout")) { c->use_fused_convout = value; return 0; }
     if (!strcmp(name, "use_convout_stream")) { c->use_convout_stream = value; return 0; }
     if (!strcmp(name, "use_wgrad_split")) { c->use_wgrad_split = value; return 0; }

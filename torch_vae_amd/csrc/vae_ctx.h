@@ -111,6 +111,7 @@ struct vae_ctx {
     // use_convout_stream: 128-pixel-wide images take the row-streaming form of that kernel (convout_stream.cuh); 0 = the tiled one
     int use_dnf_stream = 1;    // encoder.1 forward on 128x128 images: row-streaming kernel (dnfirst_stream.cuh); 0 = the tiled one
     int use_upf_stream = 1;    // row-streaming transposed-conv forward on 128x128 images (upfinal_stream.cuh): bit 0 final_layer.0, bit 1 decoder.2; 0 = the tiled kernels
+    int use_fc_dgrad8 = 1;     // fc input gradient, 16-bit storage: 8 channels x 4 rows per thread with 16-byte accesses (edge_kernels.cuh: fc_dgrad8_kernel); 0 = one channel per thread
     int use_wgrad_split = 1;   // deep weight gradients: producer / consumer wave groups (wgrad_split.cuh); 0 = the 8-wave kernel
     int use_convout_stream = 1, knob_convout_bands = 0;   // (bands per image: 0 = chosen by the launcher)
     int knob_convout_step_grid = 1024;   // (= knob_convout_bwd_grid: with the same tile partition the fused kernel and convout_bwd produce bit-identical statistics)

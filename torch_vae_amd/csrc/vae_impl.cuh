@@ -954,8 +954,23 @@ static int backward_second(vae_ctx* c, const float* x, const float* params, floa
         d.B = B; d.F = (int)c->F; d.L2 = 2 * L; d.s2 = c->s2; d.gmul = c->gmul;
         ProfScope ps2(c, "fc_dgrad", (double)sizeof(T) * (2.0 * B * c->F + 2.0 * c->F * L), 4.0 * B * c->F * L, st);
         d.bt_per_wg = std::max(16, ((B + 7) / 8 + 15) / 16 * 16);   // <= 8 workgroups per channel: fewer same-address atomics
-        hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + d.bt_per_wg - 1) / d.bt_per_wg), dim3(256), 2 * L * 16 * 4, st, d);
-        LAUNCH_CHECK("fc_dgrad_kernel");
+        bool wide = false;
+        if constexpr (sizeof(T) == 2) wide = c->use_fc_dgrad8 && fc_dgrad8_lds(2 * L, 4, 16) <= 64 * 1024;
+        if constexpr (sizeof(T) == 2) {
+            if (wide) {
+                // bit 1: 512-thread workgroups over 64 rows (half the workgroups, half the f64 atomics of the statistics)
+                const bool big = (c->use_fc_dgrad8 & 2) && B > 32;
+                d.bt_per_wg = big ? std::max(64, ((B + 3) / 4 + 63) / 64 * 64) : (d.bt_per_wg + 31) / 32 * 32;
+                const dim3 grid((unsigned)(c->F / 256), (B + d.bt_per_wg - 1) / d.bt_per_wg);
+                if (big) hipLaunchKernelGGL((fc_dgrad8_kernel<T, 4, 16>), grid, dim3(512), fc_dgrad8_lds(2 * L, 4, 16), st, d);
+                else hipLaunchKernelGGL((fc_dgrad8_kernel<T, 4, 8>), grid, dim3(256), fc_dgrad8_lds(2 * L, 4, 8), st, d);
+                LAUNCH_CHECK("fc_dgrad8_kernel");
+            }
+        }
+        if (!wide) {
+            hipLaunchKernelGGL((fc_dgrad_kernel<T>), dim3((unsigned)(c->F / 256), (B + d.bt_per_wg - 1) / d.bt_per_wg), dim3(256), 2 * L * 16 * 4, st, d);
+            LAUNCH_CHECK("fc_dgrad_kernel");
+        }
     }
     // encoder stack: Conv2d layers 3, 2, 1 on MFMA, then block 0
     for (int i = 3; i >= 1; --i) {
