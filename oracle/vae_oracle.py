@@ -270,6 +270,22 @@ def bn_train_bwd(dz, gamma, cache):
     return dy, dgamma, dbeta
 
 
+def bn_train_fwd_stored(y, gamma, beta, storage):
+    """bn_train_fwd for a STORED (already rounded) 16-bit tensor, the way the HIP kernels form the pre-activation: ONE f32 fused
+    multiply-add of the stored y with f32 coefficients derived in double (torch_vae_amd/csrc/common.cuh bn_fused_channel:
+    sc = gamma*invstd, sh = beta - mean*sc).  Where z lands within rounding of 0 this - not the exact value - decides LeakyReLU's
+    slope, so the storage emulation takes the same route.  storage None: plain bn_train_fwd."""
+    z, cache = bn_train_fwd(y, gamma, beta)
+    if storage is not None:
+        invstd, mean = cache[1].astype(np.float64), cache[2].astype(np.float64)
+        sc64 = gamma.astype(np.float64) * invstd
+        sc32 = sc64.astype(np.float32).astype(np.float64)
+        sh32 = (beta.astype(np.float64) - mean * sc64).astype(np.float32).astype(np.float64)
+        y32 = y.astype(np.float32).astype(np.float64)
+        z = (y32 * sc32.reshape(1, -1, 1, 1) + sh32.reshape(1, -1, 1, 1)).astype(np.float32).astype(y.dtype)
+    return z, cache
+
+
 def bn_eval_fwd(y, gamma, beta, rm, rv):
     invstd = 1.0 / np.sqrt(rv + y.dtype.type(BN_EPS))
     return (y - rm.reshape(1, -1, 1, 1)) * (gamma * invstd).reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
@@ -350,17 +366,7 @@ def forward(p: dict, x: np.ndarray, eps: np.ndarray, bn_state: dict | None = Non
     def bn(name, y):
         g, b = p[name + ".weight"], p[name + ".bias"]
         if train:
-            z, cache = bn_train_fwd(y, g, b)
-            if storage is not None:
-                # the kernels form the pre-activation as ONE f32 fused multiply-add of the stored y with f32 coefficients derived in
-                # double (common.cuh bn_fused_channel: sc = gamma*invstd, sh = beta - mean*sc): where z lands within rounding of 0
-                # this - not the exact value - decides LeakyReLU's slope, so the emulation takes the same route
-                invstd, mean = cache[1].astype(np.float64), cache[2].astype(np.float64)
-                sc64 = g.astype(np.float64) * invstd
-                sc32 = sc64.astype(np.float32).astype(np.float64)
-                sh32 = (b.astype(np.float64) - mean * sc64).astype(np.float32).astype(np.float64)
-                y32 = y.astype(np.float32).astype(np.float64)
-                z = (y32 * sc32.reshape(1, -1, 1, 1) + sh32.reshape(1, -1, 1, 1)).astype(np.float32).astype(y.dtype)
+            z, cache = bn_train_fwd_stored(y, g, b, storage)
             if bn_state is not None and update_running:
                 n = y.shape[0] * y.shape[2] * y.shape[3]
                 mean, var = cache[2], cache[3]

@@ -1447,3 +1447,121 @@ def test_streaming_output_conv_matches_tiled_kernel(dtype, B, bands):
     tol = {"bf16": 3e-2, "f16": 5e-3}[dtype]
     assert max(worst.values()) < tol, {k: v for k, v in worst.items() if v >= tol}
     assert max(worst[n] for n in ("final_layer.3.weight", "final_layer.3.bias", "final_layer.1.weight", "final_layer.1.bias")) < 1e-5, worst
+
+
+def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
+    """Every 16-bit kernel of the step against the storage-emulating oracle ON THE KERNEL'S OWN INPUTS: each stored tensor (y_l, dz_l,
+    decoder_input's output and gradient) and each parameter gradient is recomputed on the CPU from the tensors the GPU actually
+    stored one layer earlier, so a gap is that one kernel's, not the chain's.  (The end-to-end emulation of
+    test_every_tensor_against_oracle cannot be tighter than the chain allows: 1-ulp differences in stored activations flip
+    LeakyReLU slopes a few layers later - DESIGN.md section 4.)  Returns {tensor name: relative L2 gap}."""
+    from torch_vae_amd import _lib
+    p = perturbed_params(L, H, seed, gen)
+    x = vo.synth_pianoroll(B, H, 21).astype(np.float64)
+    eps = vo.counter_normal(B * L, 21, 5).reshape(B, L).astype(np.float64)
+    m = make_model(H, L, gen, dtype, p, kld_weight=1.0)
+    m.fused_forward_backward(torch.from_numpy(x).float().cuda(), eps=torch.from_numpy(eps).float().cuda())
+    torch.cuda.synchronize()
+    grads = flat_grad_dict(m)
+    last = {k: m._last[k].double().cpu().numpy() for k in ("xhat", "mu", "lv", "z")}
+    C = [32, 64, 128, 256, 128, 64, 32, 32]
+    s = H // 16 if gen else 2
+    HW = [H // 2, H // 4, H // 8, s, 2 * s, 4 * s, 8 * s, 16 * s]
+    gs = vo.f16_grad_scale(B, H) if dtype == "f16" else 1.0
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fetch(which, shape, scale=1.0):
+        n = int(np.prod(shape))
+        t = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, which, t.data_ptr(), n, st), "dbg")
+        torch.cuda.synchronize()
+        return t.cpu().numpy().reshape(shape).astype(np.float64) / scale
+
+    Y = [fetch(i, (B, C[i], HW[i], HW[i])) for i in range(8)]
+    DZ = [fetch(8 + i, (B, C[i], HW[i], HW[i]), gs) for i in range(8)]
+    d0 = fetch(16, (B, 256, s, s))
+    dd0 = fetch(17, (B, 256, s, s), gs)
+    names = ["encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer"]
+    rs = lambda v: vo.round_storage(v, dtype)            # noqa: E731
+    rg = lambda v: vo.round_storage(v, dtype, gs)        # noqa: E731
+    P = lambda k: p[k].astype(np.float64)                # noqa: E731
+    Z, CA = [], []
+    for i in range(8):      # pre-activations and BatchNorm caches of the GPU's stored y_l
+        z, cache = vo.bn_train_fwd_stored(Y[i], P(names[i] + ".1.weight"), P(names[i] + ".1.bias"), dtype)
+        Z.append(z); CA.append(cache)
+    A = [rs(vo.lrelu(z)) for z in Z]                      # staged operands LeakyReLU(BN(y_l)) as the next kernel rounds them
+    gaps = {}
+    G = lambda k: grads[k].reshape(p[k].shape).astype(np.float64)   # noqa: E731
+    # ---- forward, layer by layer on the GPU's own inputs
+    gaps["y0"] = rel_l2(rs(vo.conv_fwd(x, P("encoder.0.0.weight"), P("encoder.0.0.bias"), 2)), Y[0])
+    for i in (1, 2, 3):
+        gaps[f"y{i}"] = rel_l2(rs(vo.conv_fwd(A[i - 1], rs(P(names[i] + ".0.weight")), P(names[i] + ".0.bias"), 2)), Y[i])
+    pre = A[3].reshape(B, -1)
+    gaps["mu"] = rel_l2(pre @ rs(P("fc_mu.weight")).T + P("fc_mu.bias"), last["mu"])
+    gaps["log_var"] = rel_l2(pre @ rs(P("fc_var.weight")).T + P("fc_var.bias"), last["lv"])
+    gaps["z"] = rel_l2(eps * np.exp(0.5 * last["lv"]) + last["mu"], last["z"])
+    gaps["d0"] = rel_l2(rs(last["z"] @ P("decoder_input.weight").T + P("decoder_input.bias")).reshape(d0.shape), d0)
+    ins = {4: d0, 5: A[4], 6: A[5], 7: A[6]}
+    for i in (4, 5, 6, 7):
+        gaps[f"y{i}"] = rel_l2(rs(vo.convT_fwd(ins[i], rs(P(names[i] + ".0.weight")), P(names[i] + ".0.bias"))), Y[i])
+    gaps["xhat"] = rel_l2(vo.sigmoid(vo.conv_fwd(A[7], rs(P("final_layer.3.weight")), P("final_layer.3.bias"), 1)), last["xhat"])
+    # ---- backward: the output conv from the GPU's xhat, then every block from the GPU's stored (dz_l, y_l)
+    xh = last["xhat"]
+    dlogit = (xh - x) / np.maximum(xh * (1 - xh), 1e-12) / xh.size * xh * (1 - xh)
+    dl_op = rg(dlogit)
+    dw, _ = vo.conv_wgrad(A[7], dl_op, 1)
+    gaps["final_layer.3.weight"] = rel_l2(dw, G("final_layer.3.weight"))
+    gaps["final_layer.3.bias"] = rel_l2(dlogit.sum(axis=(0, 2, 3)), G("final_layer.3.bias"))
+    gaps["dz7"] = rel_l2(rg(vo.lrelu_bwd(Z[7], vo.conv_dgrad(dl_op, rs(P("final_layer.3.weight")), 1, (H, H)))), DZ[7])
+    for i in (7, 6, 5, 4, 3, 2, 1, 0):
+        n = names[i]
+        dy, dgam, dbet = vo.bn_train_bwd(DZ[i], P(n + ".1.weight"), CA[i])
+        gaps[n + ".1.weight"] = rel_l2(dgam, G(n + ".1.weight"))
+        gaps[n + ".1.bias"] = rel_l2(dbet, G(n + ".1.bias"))
+        if i == 0:          # conv1_wgrad: f32 weights, unrounded gradient operand
+            dw, db = vo.conv_wgrad(x, dy, 2)
+            gaps[n + ".0.weight"] = rel_l2(dw, G(n + ".0.weight"))
+            continue
+        dyr = rg(dy)
+        w = rs(P(n + ".0.weight"))
+        if i >= 4:
+            dx, dw, db = vo.convT_bwd(ins[i], w, dyr)
+        else:
+            dw, db = vo.conv_wgrad(A[i - 1], dyr, 2)
+            dx = vo.conv_dgrad(dyr, w, 2, A[i - 1].shape[2:])
+        gaps[n + ".0.weight"] = rel_l2(dw, G(n + ".0.weight"))
+        if i == 4:
+            gaps["dd0"] = rel_l2(rg(dx), dd0)
+            # latent block on the GPU's dd0, mu, log_var, z
+            f = dd0.reshape(B, -1)
+            gaps["decoder_input.weight"] = rel_l2(f.T @ last["z"], G("decoder_input.weight"))
+            gaps["decoder_input.bias"] = rel_l2(f.sum(axis=0), G("decoder_input.bias"))
+            dzl = f @ rs(P("decoder_input.weight"))
+            mu, lv = last["mu"], last["lv"]
+            dmu = dzl + mu / B
+            dlv = dzl * eps * np.exp(0.5 * lv) * 0.5 + 0.5 * (np.exp(lv) - 1) / B
+            act3 = vo.lrelu(Z[3]).reshape(B, -1)          # (unrounded: the fc weight gradient reads it in f32)
+            gaps["fc_mu.weight"] = rel_l2(dmu.T @ act3, G("fc_mu.weight"))
+            gaps["fc_var.weight"] = rel_l2(dlv.T @ act3, G("fc_var.weight"))
+            gaps["fc_mu.bias"] = rel_l2(dmu.sum(axis=0), G("fc_mu.bias"))
+            gaps["fc_var.bias"] = rel_l2(dlv.sum(axis=0), G("fc_var.bias"))
+            dpre = dmu @ rs(P("fc_mu.weight")) + dlv @ rs(P("fc_var.weight"))
+            gaps["dz3"] = rel_l2(rg(vo.lrelu_bwd(Z[3], dpre.reshape(Z[3].shape))), DZ[3])
+        else:
+            gaps[f"dz{i - 1}"] = rel_l2(rg(vo.lrelu_bwd(Z[i - 1], dx)), DZ[i - 1])
+    return gaps
+
+
+@pytest.mark.parametrize("dtype,H,L,B,gen", [("bf16", 32, 16, 6, False), ("f16", 32, 16, 6, False), ("bf16", 32, 10, 7, False),
+                                             ("bf16", 64, 16, 5, True), ("f16", 64, 128, 4, True), ("bf16", 128, 16, 3, True),
+                                             ("f16", 128, 16, 3, True), ("bf16", 128, 16, 9, True), ("f16", 128, 64, 8, True)])
+def test_every_kernel_against_oracle_on_its_own_inputs(dtype, H, L, B, gen):
+    """Layer-local parity of the 16-bit modes (see _layer_local_gaps): 54 tensors per case - every stored activation and gradient,
+    the latent block, xhat and every parameter gradient - each within 5e-4 (relative L2) of the storage-emulating oracle evaluated
+    on the kernel's own inputs.  Measured on MI355X: worst 1.0e-4 (a stored dz), most tensors 1e-7 .. 3e-5, many bit-identical."""
+    gaps = _layer_local_gaps(dtype, H, L, B, gen)
+    worst = max(gaps, key=gaps.get)
+    report(test="layer_local", dtype=dtype, img=H, latent=L, batch=B, worst=worst, worst_gap=gaps[worst], gaps=gaps)
+    assert len(gaps) == 54
+    bad = {k: v for k, v in gaps.items() if not v < 5e-4}
+    assert not bad, bad
