@@ -1554,11 +1554,14 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
 
 @pytest.mark.parametrize("dtype,H,L,B,gen", [("bf16", 32, 16, 6, False), ("f16", 32, 16, 6, False), ("bf16", 32, 10, 7, False),
                                              ("bf16", 64, 16, 5, True), ("f16", 64, 128, 4, True), ("bf16", 128, 16, 3, True),
-                                             ("f16", 128, 16, 3, True), ("bf16", 128, 16, 9, True), ("f16", 128, 64, 8, True)])
+                                             ("f16", 128, 16, 3, True), ("bf16", 128, 16, 9, True), ("f16", 128, 64, 8, True),
+                                             ("bf16", 128, 16, 40, True),
+                                             # BASELINE configs[1] and configs[4] (per GPU) at full size; configs[2]'s model at batch 64
+                                             ("bf16", 128, 16, 256, True), ("f16", 128, 128, 512, True), ("bf16", 256, 64, 64, True)])
 def test_every_kernel_against_oracle_on_its_own_inputs(dtype, H, L, B, gen):
     """Layer-local parity of the 16-bit modes (see _layer_local_gaps): 54 tensors per case - every stored activation and gradient,
     the latent block, xhat and every parameter gradient - each within 5e-4 (relative L2) of the storage-emulating oracle evaluated
-    on the kernel's own inputs.  Measured on MI355X: worst 1.0e-4 (a stored dz), most tensors 1e-7 .. 3e-5, many bit-identical."""
+    on the kernel's own inputs.  Measured on MI355X: worst 1.0e-4 (a stored dz; 2.3e-4 on the 256x256 model), most tensors 1e-7 .. 3e-5, many bit-identical."""
     gaps = _layer_local_gaps(dtype, H, L, B, gen)
     worst = max(gaps, key=gaps.get)
     report(test="layer_local", dtype=dtype, img=H, latent=L, batch=B, worst=worst, worst_gap=gaps[worst], gaps=gaps)
