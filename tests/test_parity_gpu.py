@@ -1482,8 +1482,9 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
     d0 = fetch(16, (B, 256, s, s))
     dd0 = fetch(17, (B, 256, s, s), gs)
     names = ["encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer"]
-    rs = lambda v: vo.round_storage(v, dtype)            # noqa: E731
-    rg = lambda v: vo.round_storage(v, dtype, gs)        # noqa: E731
+    store = None if dtype == "f32" else dtype            # (f32 mode: nothing is rounded to 16 bits; the pre-activation is still the f32 fma)
+    rs = lambda v: vo.round_storage(v, store)            # noqa: E731
+    rg = lambda v: vo.round_storage(v, store, gs)        # noqa: E731
     P = lambda k: p[k].astype(np.float64)                # noqa: E731
     Z, CA = [], []
     for i in range(8):      # pre-activations and BatchNorm caches of the GPU's stored y_l
@@ -1552,7 +1553,8 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
     return gaps
 
 
-@pytest.mark.parametrize("dtype,H,L,B,gen", [("bf16", 32, 16, 6, False), ("f16", 32, 16, 6, False), ("bf16", 32, 10, 7, False),
+@pytest.mark.parametrize("dtype,H,L,B,gen", [("f32", 32, 16, 6, False), ("f32", 64, 16, 5, True), ("f32", 128, 16, 3, True),
+                                             ("bf16", 32, 16, 6, False), ("f16", 32, 16, 6, False), ("bf16", 32, 10, 7, False),
                                              ("bf16", 64, 16, 5, True), ("f16", 64, 128, 4, True), ("bf16", 128, 16, 3, True),
                                              ("f16", 128, 16, 3, True), ("bf16", 128, 16, 9, True), ("f16", 128, 64, 8, True),
                                              ("bf16", 128, 16, 40, True),
@@ -1566,5 +1568,6 @@ def test_every_kernel_against_oracle_on_its_own_inputs(dtype, H, L, B, gen):
     worst = max(gaps, key=gaps.get)
     report(test="layer_local", dtype=dtype, img=H, latent=L, batch=B, worst=worst, worst_gap=gaps[worst], gaps=gaps)
     assert len(gaps) == 54
-    bad = {k: v for k, v in gaps.items() if not v < 5e-4}
+    gate = 1e-5 if dtype == "f32" else 5e-4       # f32 kernel mode: f32 against f64 accumulation only (measured: worst 6.2e-7)
+    bad = {k: v for k, v in gaps.items() if not v < gate}
     assert not bad, bad
