@@ -1454,7 +1454,7 @@ def test_streaming_output_conv_matches_tiled_kernel(dtype, B, bands):
     assert max(worst[n] for n in ("final_layer.3.weight", "final_layer.3.bias", "final_layer.1.weight", "final_layer.1.bias")) < 1e-5, worst
 
 
-def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
+def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None):
     """Every 16-bit kernel of the step against the storage-emulating oracle ON THE KERNEL'S OWN INPUTS: each stored tensor (y_l, dz_l,
     decoder_input's output and gradient) and each parameter gradient is recomputed on the CPU from the tensors the GPU actually
     stored one layer earlier, so a gap is that one kernel's, not the chain's.  (The end-to-end emulation of
@@ -1465,6 +1465,8 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41):
     x = vo.synth_pianoroll(B, H, 21).astype(np.float64)
     eps = vo.counter_normal(B * L, 21, 5).reshape(B, L).astype(np.float64)
     m = make_model(H, L, gen, dtype, p, kld_weight=1.0)
+    for k, v in (opts or {}).items():
+        _lib.check(_lib.lib().vae_set_option(m._context(B).handle, k.encode(), v), "set " + k)
     m.fused_forward_backward(torch.from_numpy(x).float().cuda(), eps=torch.from_numpy(eps).float().cuda())
     torch.cuda.synchronize()
     grads = flat_grad_dict(m)
@@ -1577,3 +1579,37 @@ def test_every_kernel_against_oracle_on_its_own_inputs(dtype, H, L, B, gen):
     gate = 1e-5 if dtype == "f32" else 5e-4       # f32 kernel mode: f32 against f64 accumulation only (measured: worst 6.2e-7)
     bad = {k: v for k, v in gaps.items() if not v < gate}
     assert not bad, bad
+
+
+# Every alternative kernel the library can be switched to (tiled instead of streaming, separate instead of fused, the older
+# generations kept as fallbacks for other shapes, diagnostic layouts), each through the same layer-local check as the defaults.
+KERNEL_VARIANTS = [
+    {"use_convout_stream": 0, "use_upf_stream": 0, "use_dnf_stream": 0},     # tiled forms of the three streaming kernels
+    {"use_upf_stream": 3},                                                   # both transposed-conv forwards streaming
+    {"use_fused_wgrad": 0},                                                  # separate input / weight gradient kernels on layers 7, 6, 1
+    {"use_fused_wgrad": 1}, {"use_fused_wgrad": 2},
+    {"use_wgrad_split": 0, "use_deep": 0},                                   # 8-wave weight gradients, down2 / up2 everywhere
+    {"use_deep": 3},                                                         # dn3 + up3
+    {"use_latent_mfma": 15},                                                 # the whole latent block on the exact-f32 MFMA
+    {"use_latent_mfma": 0, "use_fc_dgrad8": 0},                              # ... and on the VALU kernels
+    {"use_fc_dgrad8": 3},
+    {"use_fused_convout": 0},                                                # output conv forward, BCE and backward as separate kernels
+    {"use_pipelined": 0},                                                    # one-tile-per-workgroup conv kernels
+    {"use_raw_wgrad": 1},                                                    # materialised weight-gradient operands
+    {"use_side_stream": 0, "use_fused_bn": 0},                               # one stream, standalone BatchNorm finalisation launches
+    {"use_tr16": 0},                                                         # weight gradients without the transposed LDS reads
+    {"knob_wgrad_tile": 0}, {"knob_wgrad_wide": 0}, {"knob_wgrad_force_simple": 1},
+]
+
+
+@pytest.mark.parametrize("vi", range(len(KERNEL_VARIANTS)), ids=["+".join(f"{k}={v}" for k, v in o.items()) for o in KERNEL_VARIANTS])
+def test_every_kernel_variant_against_oracle_on_its_own_inputs(vi):
+    """The layer-local check of test_every_kernel_against_oracle_on_its_own_inputs with the library switched to each alternative kernel:
+    all 54 tensors within 5e-4 for every variant (measured on MI355X: worst 1.4e-4)."""
+    opts = KERNEL_VARIANTS[vi]
+    for dtype, H, L, B in (("bf16", 128, 16, 9), ("f16", 64, 16, 5)):
+        gaps = _layer_local_gaps(dtype, H, L, B, True, seed=43, opts=opts)
+        worst = max(gaps, key=gaps.get)
+        report(test="layer_local_variant", opts=opts, dtype=dtype, img=H, worst=worst, worst_gap=gaps[worst])
+        bad = {k: v for k, v in gaps.items() if not v < 5e-4}
+        assert not bad, (opts, dtype, bad)
