@@ -291,6 +291,19 @@ def bn_eval_fwd(y, gamma, beta, rm, rv):
     return (y - rm.reshape(1, -1, 1, 1)) * (gamma * invstd).reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
 
 
+def bn_eval_fwd_stored(y, gamma, beta, rm, rv, storage):
+    """bn_eval_fwd the way the HIP kernels form it (torch_vae_amd/csrc/edge_kernels.cuh bn_eval_coef_kernel + the consumer's staging):
+    ONE f32 fused multiply-add with f32 coefficients sc = gamma / sqrt(rv + eps), sh = beta - rm * sc derived in double.
+    storage None: plain bn_eval_fwd."""
+    if storage is None:
+        return bn_eval_fwd(y, gamma, beta, rm, rv)
+    sc64 = gamma.astype(np.float64) / np.sqrt(rv.astype(np.float64) + BN_EPS)
+    sc32 = sc64.astype(np.float32).astype(np.float64)
+    sh32 = (beta.astype(np.float64) - rm.astype(np.float64) * sc64).astype(np.float32).astype(np.float64)
+    y32 = y.astype(np.float32).astype(np.float64)
+    return (y32 * sc32.reshape(1, -1, 1, 1) + sh32.reshape(1, -1, 1, 1)).astype(np.float32).astype(y.dtype)
+
+
 def lrelu(z):
     return np.where(z > 0, z, z * z.dtype.type(LEAKY_SLOPE))
 

@@ -1613,3 +1613,67 @@ def test_every_kernel_variant_against_oracle_on_its_own_inputs(vi):
         report(test="layer_local_variant", opts=opts, dtype=dtype, img=H, worst=worst, worst_gap=gaps[worst])
         bad = {k: v for k, v in gaps.items() if not v < 5e-4}
         assert not bad, (opts, dtype, bad)
+
+
+@pytest.mark.parametrize("dtype,H,L,B,gen", [("f32", 64, 16, 5, True), ("bf16", 32, 16, 6, False), ("f16", 64, 16, 5, True),
+                                             ("bf16", 128, 16, 9, True), ("f16", 128, 16, 3, True)])
+def test_eval_mode_forward_kernels_against_oracle_on_their_own_inputs(dtype, H, L, B, gen):
+    """The forward with BatchNorm in running-statistics mode (model.eval(): evaluation.evaluate's path, evaluation.py:12-113 of the
+    reference) through the same layer-local check: every stored y_l, mu, log_var, z, decoder_input's output and x_hat recomputed on
+    the CPU from what the GPU stored one layer earlier and the running statistics it holds."""
+    from torch_vae_amd import _lib
+    p = perturbed_params(L, H, 47, gen)
+    x = vo.synth_pianoroll(B, H, 23).astype(np.float64)
+    eps = vo.counter_normal(B * L, 23, 5).reshape(B, L).astype(np.float64)
+    xt, et = torch.from_numpy(x).float().cuda(), torch.from_numpy(eps).float().cuda()
+    m = make_model(H, L, gen, dtype, p, kld_weight=1.0)
+    m.fused_forward_backward(xt, eps=et)            # a training-mode forward first: the running statistics move away from (0, 1)
+    m.eval()
+    with torch.no_grad():
+        m.set_next_eps(et)
+        out = m(xt)
+    torch.cuda.synchronize()
+    got = {"xhat": out["output"], "mu": out["encoded"]["mu"], "lv": out["encoded"]["log_var"], "z": out["latents"]}
+    got = {k: v.double().cpu().numpy() for k, v in got.items()}
+    C = [32, 64, 128, 256, 128, 64, 32, 32]
+    s = H // 16 if gen else 2
+    HW = [H // 2, H // 4, H // 8, s, 2 * s, 4 * s, 8 * s, 16 * s]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fetch(which, shape):
+        n = int(np.prod(shape))
+        t = torch.empty(n, device="cuda")
+        _lib.check(_lib.lib().vae_debug_tensor(m._ctx.handle, which, t.data_ptr(), n, st), "dbg")
+        torch.cuda.synchronize()
+        return t.cpu().numpy().reshape(shape).astype(np.float64)
+
+    Y = [fetch(i, (B, C[i], HW[i], HW[i])) for i in range(8)]
+    d0 = fetch(16, (B, 256, s, s))
+    names = ["encoder.0", "encoder.1", "encoder.2", "encoder.3", "decoder.0", "decoder.1", "decoder.2", "final_layer"]
+    store = None if dtype == "f32" else dtype
+    rs = lambda v: vo.round_storage(v, store)            # noqa: E731
+    P = lambda k: p[k].astype(np.float64)                # noqa: E731
+    bnflat = m._bnflat.double().cpu().numpy()
+    A = []
+    for i in range(8):
+        o, c = m._bn_offs[i], m._bn_ch[i]
+        rm, rv = bnflat[o:o + c], bnflat[o + c:o + 2 * c]
+        assert np.abs(rm).max() > 0                      # (moved by the training step above)
+        A.append(rs(vo.lrelu(vo.bn_eval_fwd_stored(Y[i], P(names[i] + ".1.weight"), P(names[i] + ".1.bias"), rm, rv, dtype))))
+    gaps = {"y0": rel_l2(rs(vo.conv_fwd(x, P("encoder.0.0.weight"), P("encoder.0.0.bias"), 2)), Y[0])}
+    for i in (1, 2, 3):
+        gaps[f"y{i}"] = rel_l2(rs(vo.conv_fwd(A[i - 1], rs(P(names[i] + ".0.weight")), P(names[i] + ".0.bias"), 2)), Y[i])
+    pre = A[3].reshape(B, -1)
+    gaps["mu"] = rel_l2(pre @ rs(P("fc_mu.weight")).T + P("fc_mu.bias"), got["mu"])
+    gaps["log_var"] = rel_l2(pre @ rs(P("fc_var.weight")).T + P("fc_var.bias"), got["lv"])
+    gaps["z"] = rel_l2(eps * np.exp(0.5 * got["lv"]) + got["mu"], got["z"])
+    gaps["d0"] = rel_l2(rs(got["z"] @ P("decoder_input.weight").T + P("decoder_input.bias")).reshape(d0.shape), d0)
+    ins = {4: d0, 5: A[4], 6: A[5], 7: A[6]}
+    for i in (4, 5, 6, 7):
+        gaps[f"y{i}"] = rel_l2(rs(vo.convT_fwd(ins[i], rs(P(names[i] + ".0.weight")), P(names[i] + ".0.bias"))), Y[i])
+    gaps["xhat"] = rel_l2(vo.sigmoid(vo.conv_fwd(A[7], rs(P("final_layer.3.weight")), P("final_layer.3.bias"), 1)), got["xhat"])
+    worst = max(gaps, key=gaps.get)
+    report(test="layer_local_eval", dtype=dtype, img=H, latent=L, batch=B, worst=worst, worst_gap=gaps[worst], gaps=gaps)
+    gate = 1e-5 if dtype == "f32" else 5e-4          # measured on MI355X: 7.1e-7 (f32), <= 5.2e-5 (16-bit)
+    bad = {k: v for k, v in gaps.items() if not v < gate}
+    assert not bad, bad
