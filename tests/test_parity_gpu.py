@@ -1454,7 +1454,7 @@ def test_streaming_output_conv_matches_tiled_kernel(dtype, B, bands):
     assert max(worst[n] for n in ("final_layer.3.weight", "final_layer.3.bias", "final_layer.1.weight", "final_layer.1.bias")) < 1e-5, worst
 
 
-def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None):
+def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None, kld_weight=1.0):
     """Every 16-bit kernel of the step against the storage-emulating oracle ON THE KERNEL'S OWN INPUTS: each stored tensor (y_l, dz_l,
     decoder_input's output and gradient) and each parameter gradient is recomputed on the CPU from the tensors the GPU actually
     stored one layer earlier, so a gap is that one kernel's, not the chain's.  (The end-to-end emulation of
@@ -1464,7 +1464,7 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None):
     p = perturbed_params(L, H, seed, gen)
     x = vo.synth_pianoroll(B, H, 21).astype(np.float64)
     eps = vo.counter_normal(B * L, 21, 5).reshape(B, L).astype(np.float64)
-    m = make_model(H, L, gen, dtype, p, kld_weight=1.0)
+    m = make_model(H, L, gen, dtype, p, kld_weight=kld_weight)
     for k, v in (opts or {}).items():
         _lib.check(_lib.lib().vae_set_option(m._context(B).handle, k.encode(), v), "set " + k)
     m.fused_forward_backward(torch.from_numpy(x).float().cuda(), eps=torch.from_numpy(eps).float().cuda())
@@ -1546,8 +1546,8 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None):
             gaps["decoder_input.bias"] = rel_l2(f.sum(axis=0), G("decoder_input.bias"))
             dzl = f @ rs(P("decoder_input.weight"))
             mu, lv = last["mu"], last["lv"]
-            dmu = dzl + mu / B
-            dlv = dzl * eps * np.exp(0.5 * lv) * 0.5 + 0.5 * (np.exp(lv) - 1) / B
+            dmu = dzl + kld_weight * mu / B
+            dlv = dzl * eps * np.exp(0.5 * lv) * 0.5 + kld_weight * 0.5 * (np.exp(lv) - 1) / B
             act3 = vo.lrelu(Z[3]).reshape(B, -1)          # (unrounded: the fc weight gradient reads it in f32)
             gaps["fc_mu.weight"] = rel_l2(dmu.T @ act3, G("fc_mu.weight"))
             gaps["fc_var.weight"] = rel_l2(dlv.T @ act3, G("fc_var.weight"))
@@ -1675,5 +1675,16 @@ def test_eval_mode_forward_kernels_against_oracle_on_their_own_inputs(dtype, H, 
     worst = max(gaps, key=gaps.get)
     report(test="layer_local_eval", dtype=dtype, img=H, latent=L, batch=B, worst=worst, worst_gap=gaps[worst], gaps=gaps)
     gate = 1e-5 if dtype == "f32" else 5e-4          # measured on MI355X: 7.1e-7 (f32), <= 5.2e-5 (16-bit)
+    bad = {k: v for k, v in gaps.items() if not v < gate}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,kw", [("f16", 16.0), ("bf16", 4.0), ("f32", 16.0)])
+def test_every_kernel_against_oracle_on_its_own_inputs_beta_vae(dtype, kw):
+    """BASELINE configs[4]'s beta-VAE weights (kld_weight 4 / 16, latent 128) through the layer-local check."""
+    gaps = _layer_local_gaps(dtype, 128, 128, 6, True, seed=53, kld_weight=kw)
+    worst = max(gaps, key=gaps.get)
+    report(test="layer_local_beta", dtype=dtype, kld_weight=kw, worst=worst, worst_gap=gaps[worst])
+    gate = 1e-5 if dtype == "f32" else 5e-4
     bad = {k: v for k, v in gaps.items() if not v < gate}
     assert not bad, bad
