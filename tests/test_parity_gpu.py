@@ -874,11 +874,11 @@ def test_full_size_baseline_configs(cfg):
 # BASELINE.json single-GPU configurations at FULL size against the torch-CPU oracle (oracle/torch_cpu_step.py, pinned to the
 # reference by tests/test_oracle.py): configs[1] 128x128 L16 B256, configs[2] 256x256 L64 B512, configs[4] 128x128 L128 B512 beta 16.
 # The host side of configs[2] at its full batch of 512 takes ~170 s (and two layer-local cases below ~110 s together): the default
-# run keeps the suite near five minutes by taking those three at a reduced batch - same model, same kernels, several tiles / bands
-# per workgroup - and runs configs[1] and configs[4] exactly; VAE_FULL_TESTS=1 runs every case at the exact BASELINE size (it
-# passes: profiles/r03_gpu_tests_full.txt).
+# run keeps the suite near six minutes by taking configs[2] and configs[4] at a reduced batch - same models, same kernels, several
+# tiles / bands per workgroup - and runs configs[1], the configuration the metric is quoted on, exactly; VAE_FULL_TESTS=1 runs
+# every case at the exact BASELINE size (it passes: profiles/r03_gpu_tests_full.txt).
 FULL_TESTS = os.environ.get("VAE_FULL_TESTS", "0") == "1"
-FULL_ORACLE = [(128, 16, 256, 1.0), (128, 128, 512, 16.0), (256, 64, 512 if FULL_TESTS else 64, 1.0)]
+FULL_ORACLE = [(128, 16, 256, 1.0), (128, 128, 512 if FULL_TESTS else 256, 16.0), (256, 64, 512 if FULL_TESTS else 32, 1.0)]
 
 
 @pytest.mark.parametrize("cfg", FULL_ORACLE, ids=[f"{h}x{h}-L{l}-B{b}-k{int(k)}" for h, l, b, k in FULL_ORACLE])
@@ -1564,7 +1564,6 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None, kld_weight=1.0):
                                              ("bf16", 32, 16, 6, False), ("f16", 32, 16, 6, False), ("bf16", 32, 10, 7, False),
                                              ("bf16", 64, 16, 5, True), ("f16", 64, 128, 4, True), ("bf16", 128, 16, 3, True),
                                              ("f16", 128, 16, 3, True), ("bf16", 128, 16, 9, True), ("f16", 128, 64, 8, True),
-                                             ("bf16", 128, 16, 40, True),
                                              # BASELINE configs[1] and configs[4] (per GPU) at full size; configs[2]'s model at batch 64
                                              ("bf16", 128, 16, 256, True), ("f16", 128, 128, 512 if FULL_TESTS else 64, True),
                                              ("bf16", 256, 64, 64 if FULL_TESTS else 16, True)])
@@ -1607,7 +1606,8 @@ def test_every_kernel_variant_against_oracle_on_its_own_inputs(vi):
     """The layer-local check of test_every_kernel_against_oracle_on_its_own_inputs with the library switched to each alternative kernel:
     all 54 tensors within 5e-4 for every variant (measured on MI355X: worst 1.4e-4)."""
     opts = KERNEL_VARIANTS[vi]
-    for dtype, H, L, B in (("bf16", 128, 16, 9), ("f16", 64, 16, 5)):
+    shapes = (("bf16", 128, 16, 9), ("f16", 64, 16, 5)) if (FULL_TESTS or vi % 3 == 0) else (("bf16", 128, 16, 9),)
+    for dtype, H, L, B in shapes:
         gaps = _layer_local_gaps(dtype, H, L, B, True, seed=43, opts=opts)
         worst = max(gaps, key=gaps.get)
         report(test="layer_local_variant", opts=opts, dtype=dtype, img=H, worst=worst, worst_gap=gaps[worst])
