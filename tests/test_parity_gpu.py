@@ -1454,7 +1454,7 @@ def test_streaming_output_conv_matches_tiled_kernel(dtype, B, bands):
     assert max(worst[n] for n in ("final_layer.3.weight", "final_layer.3.bias", "final_layer.1.weight", "final_layer.1.bias")) < 1e-5, worst
 
 
-def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None, kld_weight=1.0):
+def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None, kld_weight=1.0, exact_convout=False):
     """Every 16-bit kernel of the step against the storage-emulating oracle ON THE KERNEL'S OWN INPUTS: each stored tensor (y_l, dz_l,
     decoder_input's output and gradient) and each parameter gradient is recomputed on the CPU from the tensors the GPU actually
     stored one layer earlier, so a gap is that one kernel's, not the chain's.  (The end-to-end emulation of
@@ -1512,15 +1512,19 @@ def _layer_local_gaps(dtype, H, L, B, gen, seed=41, opts=None, kld_weight=1.0):
     ins = {4: d0, 5: A[4], 6: A[5], 7: A[6]}
     for i in (4, 5, 6, 7):
         gaps[f"y{i}"] = rel_l2(rs(vo.convT_fwd(ins[i], rs(P(names[i] + ".0.weight")), P(names[i] + ".0.bias"))), Y[i])
-    gaps["xhat"] = rel_l2(vo.sigmoid(vo.conv_fwd(A[7], rs(P("final_layer.3.weight")), P("final_layer.3.bias"), 1)), last["xhat"])
+    # the output conv: the MFMA kernels multiply 16-bit operands (staged a7, packed weights, dlogit); the VALU kernels kept as the
+    # fallback (use_mfma_convout = 0; also the f32 mode's path) stage a7 in f32 and read the f32 weights and dlogit (exact_convout)
+    a7 = vo.lrelu(Z[7]) if exact_convout else A[7]
+    wo = P("final_layer.3.weight") if exact_convout else rs(P("final_layer.3.weight"))
+    gaps["xhat"] = rel_l2(vo.sigmoid(vo.conv_fwd(a7, wo, P("final_layer.3.bias"), 1)), last["xhat"])
     # ---- backward: the output conv from the GPU's xhat, then every block from the GPU's stored (dz_l, y_l)
     xh = last["xhat"]
     dlogit = (xh - x) / np.maximum(xh * (1 - xh), 1e-12) / xh.size * xh * (1 - xh)
-    dl_op = rg(dlogit)
-    dw, _ = vo.conv_wgrad(A[7], dl_op, 1)
+    dl_op = dlogit if exact_convout else rg(dlogit)
+    dw, _ = vo.conv_wgrad(a7, dl_op, 1)
     gaps["final_layer.3.weight"] = rel_l2(dw, G("final_layer.3.weight"))
     gaps["final_layer.3.bias"] = rel_l2(dlogit.sum(axis=(0, 2, 3)), G("final_layer.3.bias"))
-    gaps["dz7"] = rel_l2(rg(vo.lrelu_bwd(Z[7], vo.conv_dgrad(dl_op, rs(P("final_layer.3.weight")), 1, (H, H)))), DZ[7])
+    gaps["dz7"] = rel_l2(rg(vo.lrelu_bwd(Z[7], vo.conv_dgrad(dl_op, wo, 1, (H, H)))), DZ[7])
     for i in (7, 6, 5, 4, 3, 2, 1, 0):
         n = names[i]
         dy, dgam, dbet = vo.bn_train_bwd(DZ[i], P(n + ".1.weight"), CA[i])
@@ -1598,6 +1602,7 @@ KERNEL_VARIANTS = [
     {"use_side_stream": 0, "use_fused_bn": 0},                               # one stream, standalone BatchNorm finalisation launches
     {"use_tr16": 0},                                                         # weight gradients without the transposed LDS reads
     {"knob_wgrad_tile": 0}, {"knob_wgrad_wide": 0}, {"knob_wgrad_force_simple": 1},
+    {"use_fused_convout": 0, "use_mfma_convout": 0},                         # the VALU output-conv kernels (forward and backward)
 ]
 
 
@@ -1608,7 +1613,7 @@ def test_every_kernel_variant_against_oracle_on_its_own_inputs(vi):
     opts = KERNEL_VARIANTS[vi]
     shapes = (("bf16", 128, 16, 9), ("f16", 64, 16, 5)) if (FULL_TESTS or vi % 3 == 0) else (("bf16", 128, 16, 9),)
     for dtype, H, L, B in shapes:
-        gaps = _layer_local_gaps(dtype, H, L, B, True, seed=43, opts=opts)
+        gaps = _layer_local_gaps(dtype, H, L, B, True, seed=43, opts=opts, exact_convout=opts.get("use_mfma_convout", 1) == 0)
         worst = max(gaps, key=gaps.get)
         report(test="layer_local_variant", opts=opts, dtype=dtype, img=H, worst=worst, worst_gap=gaps[worst])
         bad = {k: v for k, v in gaps.items() if not v < 5e-4}
