@@ -1693,3 +1693,53 @@ def test_every_kernel_against_oracle_on_its_own_inputs_beta_vae(dtype, kw):
     gate = 1e-5 if dtype == "f32" else 5e-4
     bad = {k: v for k, v in gaps.items() if not v < gate}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,wd", [("bf16", 0.0), ("f32", 0.01)])
+def test_adamw_kernel_against_oracle_on_its_own_inputs(dtype, wd):
+    """The fused AdamW + OneCycle update (train.py:228-238, 656-659) in the same spirit: at the third step of the one-call training
+    step the new parameters and both moments are recomputed on the CPU (f64) from the GPU's own gradients, old parameters, old
+    moments and the scheduler's (lr, beta1) of that step; the modules the reference never optimises must not move."""
+    from argparse import Namespace
+    from torch_vae_amd import _lib
+    from torch_vae_amd.train import build_optimizer, fused_step
+    H, L, B = 64, 16, 6
+    p = perturbed_params(L, H, 61, True)
+    m = make_model(H, L, True, dtype, p, kld_weight=1.0)
+    cfg = Namespace(batch_size_per_gpu=B, world_size=1, lr_relative=0.01, weight_decay=wd, optimizer="AdamW", scheduler="OneCycle", epochs=1,
+                    freeze_encoder=False)
+    opt, sched = build_optimizer(cfg, m, steps_per_epoch=10)
+    opt._bind()                                        # (the flat moment buffers are created on first use)
+    worst = {}
+    for step in range(1, 4):
+        x = torch.from_numpy(vo.synth_pianoroll(B, H, 30 + step)).cuda()
+        eps = torch.from_numpy(vo.counter_normal(B * L, 30 + step, 5).reshape(B, L)).float().cuda()
+        p0 = m.flat_parameters().double().cpu().numpy().copy()
+        m0, v0 = opt._m.double().cpu().numpy().copy(), opt._v.double().cpu().numpy().copy()
+        hyper = [(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]) for g in opt.param_groups]
+        fused_step(m, opt, x, eps=eps)
+        torch.cuda.synchronize()
+        g = m.flat_grads().double().cpu().numpy()
+        p1 = m.flat_parameters().double().cpu().numpy()
+        m1, v1 = opt._m.double().cpu().numpy(), opt._v.double().cpu().numpy()
+        touched = np.zeros(p0.size, dtype=bool)
+        for (lr, b1, b2, e, wdg), (o, n) in zip(hyper, opt._ranges):
+            sl = slice(o, o + n)
+            touched[sl] = True
+            # the C ABI carries lr / beta1 / beta2 as float (include/vae_step.h): the kernel's (1 - beta) are those of the f32 values.
+            # torch forms 1 - beta2 from the Python double (0.001 against 0.00099998712 for beta2 = 0.999): a 1.3e-5 relative
+            # difference in the second moment's increment, 6e-6 in the update - recorded in DESIGN.md section 4.
+            lr, b1, b2 = float(np.float32(lr)), float(np.float32(b1)), float(np.float32(b2))
+            mm = m0[sl] * b1 + (1 - b1) * g[sl]
+            vv = v0[sl] * b2 + (1 - b2) * g[sl] * g[sl]
+            denom = np.sqrt(vv) / np.sqrt(1 - b2 ** step) + float(np.float32(e))
+            want = p0[sl] * (1 - lr * float(np.float32(wdg))) - lr / (1 - b1 ** step) * (mm / denom)
+            for name, got_, want_ in (("param", p1[sl], want), ("exp_avg", m1[sl], mm), ("exp_avg_sq", v1[sl], vv)):
+                worst[name] = max(worst.get(name, 0.0), rel_l2(got_, want_))
+            # the update itself (p1 - p0 is ~1e-3 of p): compared on its own so that the parameter's magnitude cannot hide it
+            worst["update"] = max(worst.get("update", 0.0), rel_l2(p1[sl] - p0[sl], want - p0[sl]))
+        assert touched.sum() == sum(n for _, n in opt._ranges) and not touched.all()
+        assert np.array_equal(p1[~touched], p0[~touched])          # fc_mu, fc_var, decoder_input, final_layer: never updated (train.py:210-225)
+        sched.step()
+    report(test="adamw_local", dtype=dtype, weight_decay=wd, **worst)
+    assert worst["param"] < 1e-6 and worst["exp_avg"] < 1e-6 and worst["exp_avg_sq"] < 1e-6 and worst["update"] < 1e-4, worst
