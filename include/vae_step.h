@@ -153,18 +153,21 @@ int vae_broadcast_state(vae_ctx* ctx, float* params, float* bn_running, int64_t*
 
 /* torch.optim.AdamW.step (train.py:228,656) on up to two contiguous ranges of the flat
  * buffers (the encoder and decoder groups of train.py:210-225), each with the lr and beta1
- * OneCycleLR set for this step (train.py:233-238,659).  step is 1-based. */
+ * OneCycleLR set for this step (train.py:233-238,659).  step is 1-based.  The hyper-parameters are
+ * doubles, as torch holds them: 1 - beta, 1 - lr * weight_decay, the bias corrections and lr / bc1 are
+ * formed in double and only then rounded to the float the element-wise update uses (torch's scalar
+ * arguments: (float)(1 - 0.999) is 0.001f, not 1.f - 0.999f). */
 int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int ngroups,
-                   const int64_t* offsets, const int64_t* sizes, const float* lrs, const float* beta1s,
-                   float beta2, float eps, float weight_decay, float grad_scale, int step,
+                   const int64_t* offsets, const int64_t* sizes, const double* lrs, const double* beta1s,
+                   double beta2, double eps, double weight_decay, float grad_scale, int step,
                    vae_stream_t stream);
 
 /* One whole training step (train.py:634-659 minus logging): forward, loss, backward, AdamW. */
 int vae_train_step(vae_ctx* ctx, const float* x, int batch, float* params, float* grads, float* exp_avg,
                    float* exp_avg_sq, float* bn_running, int64_t* num_batches_tracked, const float* eps,
                    uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
-                   const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
-                   float weight_decay, int step, float* xhat, float* mu, float* log_var, float* z,
+                   const int64_t* sizes, const double* lrs, const double* beta1s, double beta2, double adam_eps,
+                   double weight_decay, int step, float* xhat, float* mu, float* log_var, float* z,
                    float* out3, vae_stream_t stream);
 
 /* The fused training step of torch_vae_amd.train.fused_step as ONE host call (train.py:634-659): forward with the output
@@ -176,8 +179,8 @@ int vae_train_step(vae_ctx* ctx, const float* x, int batch, float* params, float
 int vae_train_step_fused(vae_ctx* ctx, const float* x, int batch, float* params, float* grads, float* exp_avg,
                          float* exp_avg_sq, float* bn_running, int64_t* num_batches_tracked, const float* eps,
                          uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
-                         const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
-                         float weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu,
+                         const int64_t* sizes, const double* lrs, const double* beta1s, double beta2, double adam_eps,
+                         double weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu,
                          float* log_var, float* z, float* out3, vae_stream_t stream);
 
 /* Synthetic pianoroll/line batch with the distribution of data_generators.py:45-77

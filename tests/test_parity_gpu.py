@@ -580,7 +580,7 @@ def test_c_abi_train_step_matches_python_path():
     mom, var = torch.zeros_like(flat), torch.zeros_like(flat)
     opt._bind()
     offs = (C.c_int64 * 2)(*[r[0] for r in opt._ranges]); sizes = (C.c_int64 * 2)(*[r[1] for r in opt._ranges])
-    lrs = (C.c_float * 2)(lr, lr); b1s = (C.c_float * 2)(b1, b1)
+    lrs = (C.c_double * 2)(lr, lr); b1s = (C.c_double * 2)(b1, b1)
     xhat = torch.empty(B, 1, H, H, device="cuda"); mu = torch.empty(B, L, device="cuda"); lv = torch.empty_like(mu); z = torch.empty_like(mu)
     out3 = torch.empty(3, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -1726,14 +1726,13 @@ def test_adamw_kernel_against_oracle_on_its_own_inputs(dtype, wd):
         for (lr, b1, b2, e, wdg), (o, n) in zip(hyper, opt._ranges):
             sl = slice(o, o + n)
             touched[sl] = True
-            # the C ABI carries lr / beta1 / beta2 as float (include/vae_step.h): the kernel's (1 - beta) are those of the f32 values.
-            # torch forms 1 - beta2 from the Python double (0.001 against 0.00099998712 for beta2 = 0.999): a 1.3e-5 relative
-            # difference in the second moment's increment, 6e-6 in the update - recorded in DESIGN.md section 4.
-            lr, b1, b2 = float(np.float32(lr)), float(np.float32(b1)), float(np.float32(b2))
-            mm = m0[sl] * b1 + (1 - b1) * g[sl]
-            vv = v0[sl] * b2 + (1 - b2) * g[sl] * g[sl]
-            denom = np.sqrt(vv) / np.sqrt(1 - b2 ** step) + float(np.float32(e))
-            want = p0[sl] * (1 - lr * float(np.float32(wdg))) - lr / (1 - b1 ** step) * (mm / denom)
+            # torch's scalars: every expression below in double from the Python floats, rounded ONCE to the float the element-wise
+            # update multiplies with ((float)(1 - 0.999) = 0.001f) - the C ABI carries the hyper-parameters as doubles for that
+            f = lambda v: float(np.float32(v))        # noqa: E731
+            mm = m0[sl] * f(b1) + f(1 - b1) * g[sl]
+            vv = v0[sl] * f(b2) + f(1 - b2) * g[sl] * g[sl]
+            denom = np.sqrt(vv) * f(1 / np.sqrt(1 - b2 ** step)) + f(e)
+            want = p0[sl] * f(1 - lr * wdg) - f(lr / (1 - b1 ** step)) * (mm / denom)
             for name, got_, want_ in (("param", p1[sl], want), ("exp_avg", m1[sl], mm), ("exp_avg_sq", v1[sl], vv)):
                 worst[name] = max(worst.get(name, 0.0), rel_l2(got_, want_))
             # the update itself (p1 - p0 is ~1e-3 of p): compared on its own so that the parameter's magnitude cannot hide it

@@ -49,7 +49,8 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C torch_vae_amd/csrc`. There is no CPU fallback for the VAE step.")
     L = C.CDLL(LIB_PATH)
-    p, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    p, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
+    f64p = C.POINTER(C.c_double)
     i64p = C.POINTER(C.c_int64)
     f32p = C.POINTER(C.c_float)
     _sig(L.vae_last_error, C.c_char_p, [])
@@ -75,10 +76,10 @@ def lib():
     _sig(L.vae_comm_destroy, i32, [p])
     _sig(L.vae_allreduce_grads, i32, [p, p, i32, i64p, i64p, i32, p])
     _sig(L.vae_broadcast_state, i32, [p, p, p, p, i32, p])
-    _sig(L.vae_adamw_step, i32, [p, p, p, p, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32, i32, p])
-    _sig(L.vae_train_step, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32,
+    _sig(L.vae_adamw_step, i32, [p, p, p, p, i32, i64p, i64p, f64p, f64p, f64, f64, f64, f32, i32, p])
+    _sig(L.vae_train_step, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f64p, f64p, f64, f64, f64,
                                  i32, p, p, p, p, p, p])
-    _sig(L.vae_train_step_fused, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f32p, f32p, f32, f32, f32, f32,
+    _sig(L.vae_train_step_fused, i32, [p, p, i32, p, p, p, p, p, p, p, u64, f32, i32, i64p, i64p, f64p, f64p, f64, f64, f64, f32,
                                        i32, i32, p, p, p, p, p, p])
     _sig(L.vae_synth_pianoroll, i32, [p, i32, i32, u64, p])
     _sig(L.vae_expand_stimuli, i32, [p, i32, p, i64, p])

@@ -836,18 +836,20 @@ __global__ void pack_kernel(const PackDesc* __restrict__ descs) {
 // ---------------------------------------------------------------------------
 // torch.optim.AdamW (train.py:228) over up to two contiguous parameter ranges
 // (encoder group, decoder group), each with its own OneCycle lr / beta1 (train.py:233-238).
-struct AdamGroup { long off, n; float lr, beta1; float step_size, inv_sqrt_bc2; };   // step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t): host, in double
+// every float below is a double expression of the host rounded once (vae_adamw_step): omb1 = 1 - beta1, decay = 1 - lr * weight_decay,
+// step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t), omb2 = 1 - beta2
+struct AdamGroup { long off, n; float beta1, omb1, decay; float step_size, inv_sqrt_bc2; };
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     AdamGroup grp[2]; int ngrp;
-    float beta2, eps, weight_decay, grad_scale; int step;
+    float beta2, omb2, eps, grad_scale; int step;
 };
 // One element of torch.optim.AdamW's single-tensor update (decoupled decay, bias corrections as torch computes them).
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamGroup& gr, const AdamArgs& a, float decay) {
     g *= a.grad_scale;
     p *= decay;
-    m = m * gr.beta1 + (1.f - gr.beta1) * g;
-    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    m = m * gr.beta1 + gr.omb1 * g;
+    v = v * a.beta2 + a.omb2 * g * g;
     const float denom = sqrtf(v) * gr.inv_sqrt_bc2 + a.eps;
     p -= gr.step_size * (m / denom);
 }
@@ -856,7 +858,7 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 // division each) they cost more than the update itself.
 static __global__ void adamw_kernel(AdamArgs a) {
     const AdamGroup gr = a.grp[blockIdx.y];
-    const float decay = 1.f - gr.lr * a.weight_decay;
+    const float decay = gr.decay;
     const long n4 = (gr.off & 3) == 0 ? gr.n >> 2 : 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long k = gr.off + 4 * i;

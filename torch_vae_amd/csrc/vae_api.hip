@@ -458,19 +458,22 @@ extern "C" int vae_backward(vae_ctx* c, const float* x, const float* params, flo
 }
 
 extern "C" int vae_adamw_step(float* params, const float* grads, float* m, float* v, int ngroups, const int64_t* offsets,
-                              const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float eps, float weight_decay,
+                              const int64_t* sizes, const double* lrs, const double* beta1s, double beta2, double eps, double weight_decay,
                               float grad_scale, int step, vae_stream_t stream) {
     if (ngroups < 1 || ngroups > 2) return vae_set_error("vae_adamw_step", "1 or 2 groups");
     if (step < 1) return vae_set_error("vae_adamw_step", "step is 1-based");
     AdamArgs a;
-    a.p = params; a.g = grads; a.m = m; a.v = v; a.ngrp = ngroups; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    // every scalar of torch's single-tensor update is formed in double from the Python floats and reaches the element-wise kernel as
+    // one float: beta, 1 - beta, 1 - lr * weight_decay, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), eps
+    a.p = params; a.g = grads; a.m = m; a.v = v; a.ngrp = ngroups; a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
     a.grad_scale = grad_scale; a.step = step;
     long nmax = 0;
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     for (int i = 0; i < ngroups; ++i) {
-        a.grp[i].off = offsets[i]; a.grp[i].n = sizes[i]; a.grp[i].lr = lrs[i]; a.grp[i].beta1 = beta1s[i]; nmax = std::max<long>(nmax, sizes[i]);
-        const double bc1 = 1.0 - pow((double)beta1s[i], (double)step);   // torch.optim.AdamW: bias corrections with the CURRENT (cycled) beta1
-        a.grp[i].step_size = (float)((double)lrs[i] / bc1); a.grp[i].inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        a.grp[i].off = offsets[i]; a.grp[i].n = sizes[i]; nmax = std::max<long>(nmax, sizes[i]);
+        a.grp[i].beta1 = (float)beta1s[i]; a.grp[i].omb1 = (float)(1.0 - beta1s[i]); a.grp[i].decay = (float)(1.0 - lrs[i] * weight_decay);
+        const double bc1 = 1.0 - pow(beta1s[i], (double)step);   // torch.optim.AdamW: bias corrections with the CURRENT (cycled) beta1
+        a.grp[i].step_size = (float)(lrs[i] / bc1); a.grp[i].inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     }
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((nmax / 4 + 255) / 256 + 1, 2048), ngroups), dim3(256), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK("adamw_kernel");
@@ -479,8 +482,8 @@ extern "C" int vae_adamw_step(float* params, const float* grads, float* m, float
 
 extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, float* grads, float* m, float* v, float* bn_running,
                               int64_t* nbt, const float* eps, uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
-                              const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
-                              float weight_decay, int step, float* xhat, float* mu, float* lv, float* z, float* out3, vae_stream_t stream) {
+                              const int64_t* sizes, const double* lrs, const double* beta1s, double beta2, double adam_eps,
+                              double weight_decay, int step, float* xhat, float* mu, float* lv, float* z, float* out3, vae_stream_t stream) {
     if (vae_forward(c, x, B, params, bn_running, nbt, eps, seed, 1, xhat, mu, lv, z, stream)) return -1;
     if (vae_loss_deferred(c, kld_weight, out3, stream)) return -1;
     if (vae_backward(c, x, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kld_weight, 1, stream)) return -1;
@@ -501,8 +504,8 @@ extern "C" int vae_train_step(vae_ctx* c, const float* x, int B, float* params, 
 // Modes 1 and 2 need vae_comm_init.  Outputs (xhat, mu, log_var, z, out3) are caller-owned as in vae_forward / vae_loss.
 extern "C" int vae_train_step_fused(vae_ctx* c, const float* x, int B, float* params, float* grads, float* m, float* v, float* bn_running,
                                     int64_t* nbt, const float* eps, uint64_t seed, float kld_weight, int ngroups, const int64_t* offsets,
-                                    const int64_t* sizes, const float* lrs, const float* beta1s, float beta2, float adam_eps,
-                                    float weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu, float* lv,
+                                    const int64_t* sizes, const double* lrs, const double* beta1s, double beta2, double adam_eps,
+                                    double weight_decay, float grad_scale, int step, int exchange, float* xhat, float* mu, float* lv,
                                     float* z, float* out3, vae_stream_t stream) {
     if (!c) return vae_set_error("vae_train_step_fused", "null ctx");
     if (exchange < 0 || exchange > 2) return vae_set_error("vae_train_step_fused", "exchange must be 0, 1 or 2");

@@ -88,7 +88,7 @@ class FusedAdamW(torch.optim.Optimizer):
         n = len(self.param_groups)
         if cache is None:
             cache = ((C.c_int64 * n)(*[r[0] for r in self._ranges]), (C.c_int64 * n)(*[r[1] for r in self._ranges]),
-                     (C.c_float * n)(), (C.c_float * n)())
+                     (C.c_double * n)(), (C.c_double * n)())
             self.__dict__["_arg_cache"] = cache
         offs, sizes, lrs, b1s = cache
         g0 = self.param_groups[0]
@@ -131,8 +131,8 @@ class FusedAdamW(torch.optim.Optimizer):
         n = len(active)
         offs = (C.c_int64 * n)(*[r[0] for _, r in active])
         sizes = (C.c_int64 * n)(*[r[1] for _, r in active])
-        lrs = (C.c_float * n)(*[float(g["lr"]) for g, _ in active])
-        b1s = (C.c_float * n)(*[float(g["betas"][0]) for g, _ in active])
+        lrs = (C.c_double * n)(*[float(g["lr"]) for g, _ in active])
+        b1s = (C.c_double * n)(*[float(g["betas"][0]) for g, _ in active])
         g0 = active[0][0]
         for g, _ in active:
             if (g["betas"][1], g["eps"], g["weight_decay"]) != (g0["betas"][1], g0["eps"], g0["weight_decay"]):
